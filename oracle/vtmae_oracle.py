@@ -1,0 +1,320 @@
+"""CPU ORACLE for the M3L masked multimodal auto-encoder hot path.  *** TEST INFRASTRUCTURE ONLY ***
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file, and
+only as the checker / reported CPU baseline.  The product (`m3l_amd/`) never imports it and has no CPU
+fallback: it raises when the HIP extension is missing.
+
+What it restates (plain PyTorch on CPU, fp32 or fp64, autograd for the backward):
+
+  vt_load            /root/reference/utils/pretrain_utils.py:7-57
+  patchify           /root/reference/models/pretrain_models.py:768,775   (einops Rearrange)
+  patch embed        :769-771,776-778  (LayerNorm -> Linear -> LayerNorm, eps 1e-5)
+  modality + sincos  :120-143,202-214
+  mask sampling      :223-248   (Python-double int() truncation; argsort of injected noise, STABLE ascending)
+  gathers            :255-262
+  transformer        vit-pytorch==1.6.4 `vit_pytorch.vit.Transformer`  (third party, NOT in /root/reference)
+  un-shuffle         :279-307
+  heads + loss       :327-340
+  get_embeddings     :588-668
+  SinusoidalEmbed    /root/reference/tactile_ssl/model/layers/patch_embed.py:133-224 (+ create_ndgrid utils/__init__.py:39-69)
+  apply_masks        /root/reference/tactile_ssl/utils/__init__.py:25-36
+  DINO-style VTT     /root/reference/models/VTT.py:280-360,424-426
+
+PINNING.  Checked (tests/test_oracle_golden.py) against fixtures in tests/golden/*.npz produced by
+EXECUTING the reference's own `VTT`/`VTMAE`/`vt_load` code in the build container
+(tests/golden/make_golden.py).  The reference has no numeric tests or golden vectors of its own
+(SURVEY.md section 4).  The two arithmetic third-party dependencies (vit-pytorch 1.6.4 Transformer,
+positional-encodings 6.0.1 PositionalEncoding2D) are absent from the image and from /root/reference;
+they are restated from their published algorithm on BOTH sides of the fixture comparison, so that part
+is **parity unpinned** (nothing executable pins it to the real wheels).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class OracleCfg:
+    image_hw: int
+    tactile_hw: int
+    image_patch: int
+    tactile_patch: int
+    dim: int
+    depth: int
+    heads: int
+    mlp: int
+    channels: int
+    num_tactiles: int
+    dec_dim: int
+    dec_depth: int
+    dec_heads: int
+    ratio: float
+    dim_head: int = 64
+    dec_dim_head: int = 64
+
+    @property
+    def n_img(self):
+        return (self.image_hw // self.image_patch) ** 2
+
+    @property
+    def n_tac(self):
+        return (self.tactile_hw // self.tactile_patch) ** 2
+
+    @property
+    def n_total(self):
+        return self.n_img + self.num_tactiles * self.n_tac
+
+
+# ----------------------------------------------------------------------------------------------------
+# integer / index work (numpy)
+# ----------------------------------------------------------------------------------------------------
+def mask_counts(ratio: float, n_img: int, n_tac_total: int, num_tactiles: int):
+    """pretrain_models.py:223-227 with Python double semantics and int() truncation."""
+    n = n_img + n_tac_total
+    num_masked = int(ratio * n)
+    image_perc = n_img / n
+    nm_img = int(num_masked * image_perc)
+    nm_tac = (num_masked - nm_img) // num_tactiles if (num_tactiles > 0 and n_tac_total > 0) else 0
+    return num_masked, nm_img, nm_tac
+
+
+def stable_argsort_rows(noise: np.ndarray) -> np.ndarray:
+    """Ascending, ties broken by ascending original index (contract of the HIP mask kernel)."""
+    return np.argsort(noise, axis=-1, kind="stable").astype(np.int64)
+
+
+def mask_indices(noises: List[np.ndarray], ratio: float, n_img: int, n_tac: int, num_tactiles: int, perms=None):
+    """pretrain_models.py:229-248.  noises = [image (B,n_img), tactile_1 (B,n_tac), ...] in RNG order.
+    Returns (masked_indices, unmasked_indices, nm_img, nm_tac) as int64 (B, *).
+
+    Tie-break contract: STABLE ascending (== torch.argsort(stable=True)).  The reference calls
+    `torch.rand(...).argsort(dim=-1)` WITHOUT stable=True; on float32 ties torch's default sort is not stable
+    (observed here on 64-wide rows, and its CUDA kernel differs again), i.e. the reference's own order of tied
+    keys is unspecified.  `perms` lets a test inject the permutations a particular reference run produced."""
+    _, nm_img, nm_tac = mask_counts(ratio, n_img, n_tac * num_tactiles, num_tactiles)
+    perm = stable_argsort_rows(noises[0]) if perms is None else np.asarray(perms[0], dtype=np.int64)
+    masked = [perm[:, :nm_img]]
+    unmasked = [perm[:, nm_img:]]
+    count = n_img
+    for i in range(num_tactiles):
+        p = (stable_argsort_rows(noises[1 + i]) if perms is None else np.asarray(perms[1 + i], dtype=np.int64)) + count
+        masked.append(p[:, :nm_tac])
+        unmasked.append(p[:, nm_tac:])
+        count += n_tac
+    return np.concatenate(masked, 1), np.concatenate(unmasked, 1), nm_img, nm_tac
+
+
+# ----------------------------------------------------------------------------------------------------
+# float work (torch CPU)
+# ----------------------------------------------------------------------------------------------------
+def vt_load(obs: Dict[str, np.ndarray], frame_stack: int = 1) -> Dict[str, torch.Tensor]:
+    """utils/pretrain_utils.py:7-57 (image_normalization [0,1], tactile_normalization [-1,1])."""
+    out = {}
+    if "image" in obs:
+        img = np.asarray(obs["image"])
+        if img.ndim == 3:
+            img = img[None]
+        assert img.shape[-1] == 3 * frame_stack
+        out["image"] = torch.tensor(img, dtype=torch.float32).permute(0, 3, 1, 2)
+    if "tactile" in obs:
+        tac = np.asarray(obs["tactile"])
+        if tac.ndim == 3:
+            tac = tac[None]
+        assert tac.shape[1] in (3 * frame_stack, 6 * frame_stack, 12 * frame_stack)
+        n_tactiles = tac.shape[1] // frame_stack
+        idx = np.array([i * n_tactiles + c for i in range(frame_stack) for c in range(3)])
+        for s in range(n_tactiles // 3):
+            t = torch.tensor(tac[:, idx + 3 * s], dtype=torch.float32)
+            out[f"tactile{s + 1}"] = (t + 1.0) / 2.0
+    return out
+
+
+def patchify(x: torch.Tensor, p: int) -> torch.Tensor:
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)'"""
+    B, C, H, W = x.shape
+    x = x.reshape(B, C, H // p, p, W // p, p)
+    return x.permute(0, 2, 4, 3, 5, 1).reshape(B, (H // p) * (W // p), p * p * C)
+
+
+def sincos_2d(channels_param: int, gh: int, gw: int, out_ch: int, dtype=torch.float32) -> torch.Tensor:
+    """positional-encodings 6.0.1 PositionalEncoding2D(channels_param) applied to a (1,gh,gw,out_ch) tensor,
+    flattened to (gh*gw, out_ch).  Interleaved sin/cos, x-code then y-code, truncated to out_ch."""
+    ch = int(math.ceil(channels_param / 4) * 2)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+
+    def emb(n):
+        s = torch.einsum("i,j->ij", torch.arange(n).float(), inv_freq)
+        return torch.stack((s.sin(), s.cos()), dim=-1).flatten(-2, -1)
+    e = torch.zeros(gh, gw, 2 * ch)
+    e[:, :, :ch] = emb(gh).unsqueeze(1)
+    e[:, :, ch:] = emb(gw)
+    return e[:, :, :out_ch].reshape(gh * gw, -1).to(dtype)
+
+
+def transformer(x, P: Dict[str, torch.Tensor], prefix: str, depth: int, heads: int, dim_head: int,
+                final_norm: bool = True):
+    """vit-pytorch 1.6.4 Transformer forward (pre-norm attention + GELU FFN, final LayerNorm)."""
+    B, n, D = x.shape
+    for i in range(depth):
+        a = f"{prefix}layers.{i}.0."
+        f = f"{prefix}layers.{i}.1.net."
+        h = F.layer_norm(x, (D,), P[a + "norm.weight"], P[a + "norm.bias"], 1e-5)
+        qkv = h @ P[a + "to_qkv.weight"].t()
+        q, k, v = [t.reshape(B, n, heads, dim_head).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+        dots = (q @ k.transpose(-1, -2)) * (dim_head ** -0.5)
+        o = (dots.softmax(dim=-1) @ v).transpose(1, 2).reshape(B, n, heads * dim_head)
+        if (a + "to_out.0.weight") in P:
+            o = o @ P[a + "to_out.0.weight"].t() + P[a + "to_out.0.bias"]
+        x = o + x
+        h = F.layer_norm(x, (D,), P[f + "0.weight"], P[f + "0.bias"], 1e-5)
+        h = F.gelu(h @ P[f + "1.weight"].t() + P[f + "1.bias"])
+        x = h @ P[f + "4.weight"].t() + P[f + "4.bias"] + x
+    if final_norm:
+        x = F.layer_norm(x, (D,), P[prefix + "norm.weight"], P[prefix + "norm.bias"], 1e-5)
+    return x
+
+
+def _embed(patches, P, key):
+    pd = patches.shape[-1]
+    h = F.layer_norm(patches, (pd,), P[key + ".1.weight"], P[key + ".1.bias"], 1e-5)
+    h = h @ P[key + ".2.weight"].t() + P[key + ".2.bias"]
+    return F.layer_norm(h, (h.shape[-1],), P[key + ".3.weight"], P[key + ".3.bias"], 1e-5)
+
+
+def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=True, use_tactile=True):
+    """patchify + embed + modality + sincos for ALL patches (pretrain_models.py:154-216)."""
+    dt = P["mask_token"].dtype
+    toks, img_patches, tac_patches = [], None, None
+    if use_vision:
+        img_patches = patchify(x["image"].to(dt), cfg.image_patch)
+        t = _embed(img_patches, P, "encoder.image_to_patch_embedding")
+        t = t + P["encoder_modality_embedding.weight"][0] + P["image_enc_pos_embedding"][0]
+        toks.append(t)
+    if cfg.num_tactiles > 0 and use_tactile:
+        tac_patches = torch.cat([patchify(x[f"tactile{i + 1}"].to(dt), cfg.tactile_patch) for i in range(cfg.num_tactiles)], 1)
+        t = _embed(tac_patches, P, "encoder.tactile_to_patch_embedding")
+        mod = P["encoder_modality_embedding.weight"][1:1 + cfg.num_tactiles].repeat_interleave(cfg.n_tac, 0)
+        t = t + mod + P["tactile_enc_pos_embedding"][0]
+        toks.append(t)
+    return torch.cat(toks, 1), img_patches, tac_patches
+
+
+def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch.Tensor],
+                  noises: List[torch.Tensor], use_vision=True, use_tactile=True, perms=None) -> Dict[str, torch.Tensor]:
+    """VTMAE.forward (pretrain_models.py:146-342), early_conv_masking=False, use_sincosmod_encodings=True.
+    Returns every intermediate the fixtures record plus 'loss'."""
+    nt = cfg.num_tactiles if use_tactile else 0
+    n_img = cfg.n_img if use_vision else 0
+    tokens, img_patches, tac_patches = encoder_tokens(P, cfg, x, use_vision, use_tactile)
+    B = tokens.shape[0]
+    masked, unmasked, nm_img, nm_tac = mask_indices([np.asarray(z) for z in noises], cfg.ratio, n_img, cfg.n_tac, nt, perms)
+    masked_t, unmasked_t = torch.from_numpy(masked), torch.from_numpy(unmasked)
+    br = torch.arange(B)[:, None]
+    vis = tokens[br, unmasked_t]
+    out = {"masked_indices": masked_t, "unmasked_indices": unmasked_t, "tokens_all": tokens, "encoder_in": vis}
+    enc = transformer(vis, P, "encoder.transformer.", cfg.depth, cfg.heads, cfg.dim_head)
+    out["encoder_out"] = enc
+    dec_in = enc @ P["enc_to_dec.weight"].t() + P["enc_to_dec.bias"] if "enc_to_dec.weight" in P else enc
+    N = tokens.shape[1]
+    full = torch.zeros(B, N, cfg.dec_dim, dtype=tokens.dtype)
+    full = full.index_put((br, unmasked_t), dec_in)
+    full = full.index_put((br, masked_t), P["mask_token"].expand(B, masked_t.shape[1], -1))
+    add = []
+    if use_vision:
+        add.append(P["decoder_modality_embedding.weight"][0] + P["image_dec_pos_embedding"][0])
+    if nt > 0:
+        add.append(P["decoder_modality_embedding.weight"][1:1 + nt].repeat_interleave(cfg.n_tac, 0) + P["tactile_dec_pos_embedding"][0])
+    full = full + torch.cat(add, 0)
+    out["decoder_in"] = full
+    dec = transformer(full, P, "decoder.", cfg.dec_depth, cfg.dec_heads, cfg.dec_dim_head)
+    out["decoder_out"] = dec
+    loss = torch.zeros((), dtype=tokens.dtype)
+    mi_img, mi_tac = masked_t[:, :nm_img], masked_t[:, nm_img:]
+    if nt > 0:
+        pred_t = dec[br, mi_tac] @ P["to_tactiles.weight"].t() + P["to_tactiles.bias"]
+        tgt_t = tac_patches[br, mi_tac - n_img]
+        out["pred_tactile"], out["target_tactile"] = pred_t, tgt_t
+        loss = loss + 10 * F.mse_loss(pred_t, tgt_t)
+    if use_vision:
+        pred_i = dec[br, mi_img] @ P["to_pixels.weight"].t() + P["to_pixels.bias"]
+        tgt_i = img_patches[br, mi_img]
+        out["pred_pixel"], out["target_pixel"] = pred_i, tgt_i
+        loss = loss + F.mse_loss(pred_i, tgt_i)
+    out["loss"] = loss
+    return out
+
+
+def get_embeddings(P, cfg: OracleCfg, x, use_vision=True, use_tactile=True):
+    """VTMAE.get_embeddings (pretrain_models.py:588-668): encoder over ALL tokens, no masking."""
+    tokens, _, _ = encoder_tokens(P, cfg, x, use_vision, use_tactile)
+    return transformer(tokens, P, "encoder.transformer.", cfg.depth, cfg.heads, cfg.dim_head)
+
+
+# ----------------------------------------------------------------------------------------------------
+# DINO-style VTT path (models/VTT.py) pieces
+# ----------------------------------------------------------------------------------------------------
+def sinusoidal_embed(grid_hw, embed_dim: int) -> torch.Tensor:
+    """tactile_ssl/model/layers/patch_embed.py:133-224 for a 2-D grid with un-normalised integer coords:
+    nb = ceil(D/4); bands = 10000^-linspace(0,1,nb+1)[:-1]; feats = grid[...,None]*bands -> cat(sin,cos)
+    over the band axis -> flatten (coord-major) -> [:D]."""
+    gh, gw = grid_hw
+    nb = int(math.ceil(embed_dim / 4))
+    bands = 10000.0 ** (-torch.linspace(0, 1, nb + 1)[:-1])
+    ys, xs = torch.meshgrid(torch.arange(gh).float(), torch.arange(gw).float(), indexing="ij")
+    grid = torch.stack([ys, xs], -1)                       # (gh,gw,2)
+    feats = grid[..., None] * bands                        # (gh,gw,2,nb)
+    emb = torch.cat([feats.sin(), feats.cos()], dim=-1)    # (gh,gw,2,2nb)
+    return emb.flatten(-2).reshape(gh * gw, -1)[:, :embed_dim]
+
+
+def apply_masks(x: torch.Tensor, masks: List[torch.Tensor]) -> torch.Tensor:
+    """tactile_ssl/utils/__init__.py:25-36: gather kept indices per mask, concat over masks on batch."""
+    return torch.cat([torch.gather(x, 1, m[:, :, None].expand(-1, -1, x.shape[-1])) for m in masks], 0)
+
+
+def load_fixture_params(npz, dtype=torch.float32, requires_grad=False) -> Dict[str, torch.Tensor]:
+    P = {}
+    for k in npz.files:
+        if k.startswith("param/"):
+            t = torch.tensor(npz[k]).to(dtype)
+            if requires_grad and t.is_floating_point():
+                t.requires_grad_(True)
+            P[k[len("param/"):]] = t
+    return P
+
+
+def cfg_from_meta(meta, ratio) -> OracleCfg:
+    m = [int(v) for v in meta]
+    return OracleCfg(image_hw=m[0], tactile_hw=m[1], image_patch=m[2], tactile_patch=m[3], dim=m[4], depth=m[5],
+                     heads=m[6], mlp=m[7], channels=m[8], num_tactiles=m[9], dec_dim=m[10], dec_depth=m[11],
+                     dec_heads=m[12], ratio=float(ratio))
+
+
+def vtt_dino_forward(P, *, image_patch: int, tactile_patch: int, depth: int, heads: int, x, masks=None,
+                     dim_head: int = 64):
+    """models/VTT.py:280-360: three separate LN-Linear-LN embeds, one sinusoidal table over the stacked
+    (3*H/P, W/P) grid sliced per modality (:290-292), optional keep-index masks applied to each modality with the
+    SAME indices (:299-301) and concatenated over the mask list on batch, vit-pytorch Transformer (with its own
+    final LayerNorm), then `self.norm` = LayerNorm(eps=1e-6) (:165,206,354)."""
+    e1 = _embed(patchify(x["image"], image_patch), P, "image_to_patch_embedding")
+    e2 = _embed(patchify(x["tactile1"], tactile_patch), P, "tactile_to_patch_embedding_1")
+    e3 = _embed(patchify(x["tactile2"], tactile_patch), P, "tactile_to_patch_embedding_2")
+    H, W = x["image"].shape[-2:]
+    D = e1.shape[-1]
+    pos = sinusoidal_embed((3 * H // image_patch, W // image_patch), D).to(e1.dtype)
+    n1, n2 = e1.shape[1], e2.shape[1]
+    e1 = e1 + pos[:n1]
+    e2 = e2 + pos[n1:2 * n2]
+    e3 = e3 + pos[2 * n1:]
+    if masks is not None:
+        e1, e2, e3 = apply_masks(e1, masks), apply_masks(e2, masks), apply_masks(e3, masks)
+    t = torch.cat([e1, e2, e3], dim=1)
+    pre = transformer(t, P, "transformer.", depth, heads, dim_head)
+    xn = F.layer_norm(pre, (D,), P["norm.weight"], P["norm.bias"], 1e-6)
+    return {"x_prenorm": pre, "x_norm_patchtokens": xn}

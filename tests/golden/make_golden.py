@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference is mounted).
+
+Executes the REFERENCE's own `VTT` + `VTMAE` (`/root/reference/models/pretrain_models.py:59-786`) and
+`vt_load` (`/root/reference/utils/pretrain_utils.py:7-57`) on CPU fp32 and dumps small `.npz` fixtures
+(weights by state-dict key, inputs, injected mask noise, indices, intermediates, loss, all grads) into
+tests/golden/. The reference source is imported from where it lies; nothing of it is copied.
+
+How the import is made possible (ordinary ModuleNotFoundError otherwise):
+  * inert stubs for NON-arithmetic imports (gymnasium, stable_baselines3.*, cv2) that VTT/VTMAE never
+    call on this path;
+  * restated third-party arithmetic (vit-pytorch 1.6.4 Transformer, positional-encodings 6.0.1
+    PositionalEncoding2D) from tests/golden/_thirdparty_restated.py  -> that part is "parity unpinned".
+
+Mask noise: the reference draws `torch.rand(batch, n)` per modality (pretrain_models.py:229,237); we
+replace `torch.rand` for the duration of the forward by a queue of pre-generated noise tensors so the
+same noise can be handed to the oracle and to the HIP path.
+
+Usage:  python tests/golden/make_golden.py        (rewrites tests/golden/*.npz)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _install_stubs():
+    sys.path.insert(0, HERE)
+    import _thirdparty_restated as tp
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:  # inert base classes for the SB3 policy/extractor classes defined in the same file
+        def __init__(self, *a, **k):
+            pass
+
+    vp = mod("vit_pytorch")
+    vp.vit = mod("vit_pytorch.vit", pair=tp.pair, Transformer=tp.Transformer)
+    pe = mod("positional_encodings")
+    pe.torch_encodings = mod("positional_encodings.torch_encodings", PositionalEncoding2D=tp.PositionalEncoding2D)
+    gym = mod("gymnasium", Space=_Dummy)
+    gym.spaces = mod("gymnasium.spaces", Space=_Dummy, Dict=_Dummy, Box=_Dummy)
+    sb3 = mod("stable_baselines3")
+    sb3.common = mod("stable_baselines3.common")
+    mod("stable_baselines3.common.torch_layers", BaseFeaturesExtractor=torch.nn.Module, FlattenExtractor=_Dummy)
+    mod("stable_baselines3.common.type_aliases", Schedule=object)
+    mod("stable_baselines3.common.policies", ActorCriticPolicy=torch.nn.Module)
+    mod("stable_baselines3.common.logger", Video=_Dummy)
+    mod("cv2")
+    mod("omegaconf", DictConfig=_Dummy, OmegaConf=_Dummy)   # only reached through tactile_ssl/utils/logging.py:8
+    lt = mod("lightning")                                    # tactile_ssl/utils/logging.py:16 (rank-zero log decorator)
+    lt.fabric = mod("lightning.fabric")
+    lt.fabric.utilities = mod("lightning.fabric.utilities", rank_zero_only=lambda f: f)
+
+
+def _load_reference():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_pretrain_models", os.path.join(REF, "models", "pretrain_models.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+class _RandQueue:
+    """Context manager: torch.rand(...) pops pre-generated noise (shape-checked)."""
+
+    def __init__(self, noises):
+        self.noises = list(noises)
+        self.real = torch.rand
+
+    def __enter__(self):
+        def fake(*shape, device=None, **kw):
+            n = self.noises.pop(0)
+            assert tuple(n.shape) == tuple(shape), (n.shape, shape)
+            return n.clone()
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self.real
+        assert not self.noises, "unused noise tensors"
+
+
+def _noise(gen, B, n, tie_row=None):
+    x = torch.rand(B, n, generator=gen)
+    if tie_row is not None and n >= 6:
+        # crafted ties: float32-equal keys in one row (stable-ascending tie-break contract)
+        x[tie_row, 1] = x[tie_row, 4]
+        x[tie_row, 2] = x[tie_row, 4]
+        x[tie_row, n - 1] = x[tie_row, 0]
+    return x
+
+
+def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp, C, num_tactiles,
+             dec_dim, dec_depth, dec_heads, ratio, B, seed, with_embeddings=False):
+    torch.manual_seed(seed)
+    enc = ref.VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp_,
+                  dim=dim, depth=depth, heads=heads, mlp_dim=mlp, image_channels=C, tactile_channels=C,
+                  num_tactiles=num_tactiles)
+    mae = ref.VTMAE(encoder=enc, decoder_dim=dec_dim, masking_ratio=ratio, decoder_depth=dec_depth,
+                    decoder_heads=dec_heads, num_tactiles=num_tactiles, early_conv_masking=False,
+                    use_sincosmod_encodings=True)
+    # make LN affine / biases non-trivial so that every parameter is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n_, p in mae.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    mae.train()
+
+    g = torch.Generator().manual_seed(seed + 2)
+    x = {"image": torch.rand(B, C, image_hw, image_hw, generator=g)}
+    for i in range(num_tactiles):
+        x[f"tactile{i + 1}"] = torch.rand(B, C, tactile_hw, tactile_hw, generator=g)
+    n_img = (image_hw // ip) ** 2
+    n_tac = (tactile_hw // tp_) ** 2
+    noises = [_noise(g, B, n_img, tie_row=0)] + [_noise(g, B, n_tac, tie_row=(B - 1 if i == 0 else None)) for i in range(num_tactiles)]
+
+    cap = {}
+
+    def hook(key):
+        def f(mod, inp, out):
+            cap[key + "_in"] = inp[0].detach().clone()
+            cap[key + "_out"] = out.detach().clone()
+        return f
+
+    hs = [mae.encoder.transformer.register_forward_hook(hook("encoder")),
+          mae.decoder.register_forward_hook(hook("decoder")),
+          mae.to_pixels.register_forward_hook(hook("to_pixels")),
+          mae.to_tactiles.register_forward_hook(hook("to_tactiles")),
+          mae.image_patch_to_emb.register_forward_hook(hook("image_embed")),
+          mae.tactile_patch_to_emb.register_forward_hook(hook("tactile_embed"))]
+    with _RandQueue(noises):
+        loss = mae({k: v.clone() for k, v in x.items()})
+    for h in hs:
+        h.remove()
+    loss.backward()
+
+    out = {}
+    for k, v in mae.state_dict().items():
+        out["param/" + k] = v.detach().numpy()
+    for k, p in mae.named_parameters():
+        if p.grad is not None:
+            out["grad/" + k] = p.grad.detach().numpy()
+    for k, v in x.items():
+        out["input/" + k] = v.numpy()
+    for i, nz in enumerate(noises):
+        out[f"noise/{i}"] = nz.numpy()
+        out[f"argsort/{i}"] = nz.argsort(dim=-1).numpy()      # the reference's own expression (:229,:237)
+    for k, v in cap.items():
+        out["cap/" + k] = v.numpy()
+    out["loss"] = loss.detach().numpy()
+    out["meta"] = np.array([image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp, C, num_tactiles,
+                            dec_dim, dec_depth, dec_heads, B], dtype=np.int64)
+    out["ratio"] = np.array(ratio, dtype=np.float64)
+    out["unused_params"] = np.array([k for k, p in mae.named_parameters() if p.grad is None])
+
+    if with_embeddings:
+        with torch.no_grad():
+            emb = mae.get_embeddings({k: v.clone() for k, v in x.items()}, eval=True)
+        out["embeddings"] = emb.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: loss={float(loss):.8f}  keys={len(out)}")
+
+
+def run_vt_load(ref):
+    import utils.pretrain_utils as pu  # the reference's own file (cv2 / SB3 logger stubbed)
+    g = np.random.default_rng(7)
+    for fs in (1, 2):
+        obs = {"image": g.random((2, 8, 8, 3 * fs), dtype=np.float32),
+               "tactile": (g.random((2, 6 * fs, 4, 4), dtype=np.float32) * 2 - 1)}
+        o = pu.vt_load({k: v.copy() for k, v in obs.items()}, frame_stack=fs)
+        out = {"in/" + k: v for k, v in obs.items()}
+        out.update({"out/" + k: v.numpy() for k, v in o.items()})
+        np.savez_compressed(os.path.join(HERE, f"vt_load_fs{fs}.npz"), **out)
+        print(f"vt_load_fs{fs}: keys={sorted(o.keys())}")
+
+
+def run_vtt_dino():
+    """DINO-style encoder `models/VTT.py:77-426` (forward / forward_features / prepare_tokens_with_masks),
+    `SinusoidalEmbed` (tactile_ssl/model/layers/patch_embed.py:133-224) and `apply_masks`
+    (tactile_ssl/utils/__init__.py:25-36).  `tactile_ssl/model/__init__.py` pulls torchvision through
+    pretrained.py, so the `tactile_ssl.model` package object is created bare (its __path__ points at the real
+    directory) and `tactile_ssl.model.layers` is imported from the reference's own files."""
+    import tactile_ssl  # imports cleanly
+    pkg = types.ModuleType("tactile_ssl.model")
+    pkg.__path__ = [os.path.join(REF, "tactile_ssl", "model")]
+    sys.modules["tactile_ssl.model"] = pkg
+    spec = importlib.util.spec_from_file_location("ref_VTT", os.path.join(REF, "models", "VTT.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    torch.manual_seed(21)
+    B, D = 2, 64
+    enc = m.VTT(image_size=32, tactile_size=32, image_patch_size=8, tactile_patch_size=8, dim=D, depth=2, heads=2,
+                mlp_dim=128, num_tactiles=2, num_register_tokens=0)
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for n_, p in enc.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    x = {k: torch.rand(B, 3, 32, 32, generator=g) for k in ("image", "tactile1", "tactile2")}
+    masks = [torch.stack([torch.randperm(16, generator=g)[:5] for _ in range(B)]),
+             torch.stack([torch.randperm(16, generator=g)[:5] for _ in range(B)])]
+    enc.eval()
+    with torch.no_grad():
+        full = enc.forward_features({k: v.clone() for k, v in x.items()})
+        mk = enc({k: v.clone() for k, v in x.items()}, masks)
+        pos = enc.pos_embed(torch.device("cpu"))
+    out = {"param/" + k: v.numpy() for k, v in enc.state_dict().items()}
+    out.update({"input/" + k: v.numpy() for k, v in x.items()})
+    out["mask/0"], out["mask/1"] = masks[0].numpy(), masks[1].numpy()
+    out["pos_embed"] = pos.numpy()
+    out["full/x_norm_patchtokens"] = full["x_norm_patchtokens"].numpy()
+    out["full/x_prenorm"] = full["x_prenorm"].numpy()
+    out["masked/x_norm_patchtokens"] = mk.numpy()
+    emb = torch.rand(B, 16, 8, generator=g)
+    out["apply_masks/in"] = emb.numpy()
+    out["apply_masks/out"] = m.apply_masks(emb, masks).numpy()
+    out["meta"] = np.array([32, 8, D, 2, 2, 128, B], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "vtt_dino_small.npz"), **out)
+    print("vtt_dino_small: patchtokens", tuple(mk.shape), "pos", tuple(pos.shape))
+
+
+def main():
+    ref = _load_reference()
+    # A: vision + 2 tactile, the cfg-2 structure at reduced widths (D == dd -> enc_to_dec is Identity)
+    run_case(ref, "vt_small", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=2, heads=2, mlp=128, C=3,
+             num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=11, with_embeddings=True)
+    # B: vision only (cfg-1 structure), num_tactiles = 0
+    run_case(ref, "v_only_small", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=2, heads=1, mlp=128, C=3,
+             num_tactiles=0, dec_dim=64, dec_depth=1, dec_heads=1, ratio=0.75, B=2, seed=12)
+    # C: dd != D (enc_to_dec Linear + truncated decoder sincos), frame_stack-like channels, reference mask ratio
+    run_case(ref, "vt_decdim", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=128, depth=1, heads=2, mlp=256, C=6,
+             num_tactiles=2, dec_dim=64, dec_depth=2, dec_heads=1, ratio=0.95, B=2, seed=13, with_embeddings=True)
+    # D: cfg-2 token geometry exactly (64x64/P8 + 2x 32x32/P4 -> 192 tokens, 48 visible), narrow model
+    run_case(ref, "vt_cfg2_geom", image_hw=64, tactile_hw=32, ip=8, tp_=4, dim=64, depth=1, heads=1, mlp=64, C=3,
+             num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=1, ratio=0.75, B=2, seed=14)
+    run_vt_load(ref)
+    run_vtt_dino()
+
+
+if __name__ == "__main__":
+    main()

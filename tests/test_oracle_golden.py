@@ -1,0 +1,157 @@
+"""Pins the CPU oracle (oracle/vtmae_oracle.py) against the golden vectors produced by executing the reference's
+own VTT / VTMAE / vt_load (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vtmae_oracle as O
+
+CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _inputs(z):
+    x = {k[len("input/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("input/")}
+    noises = [torch.tensor(z[f"noise/{i}"]) for i in range(len([k for k in z.files if k.startswith("noise/")]))]
+    return x, noises
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_mask_indices_bit_exact(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    _, noises = _inputs(z)
+    # On tie-free rows the stable argsort IS what torch.argsort produced inside the reference run.  On rows with
+    # float32 ties the reference's order of the tied keys is unspecified (argsort without stable=True; torch's CPU
+    # sort is observably unstable on 64-wide rows): there we require the same sorted key sequence and the stable
+    # (ascending-index) tie-break of our contract == torch.argsort(stable=True).
+    saw_tie = False
+    for i, nz in enumerate(noises):
+        a = nz.numpy()
+        mine, ref = O.stable_argsort_rows(a), z[f"argsort/{i}"]
+        assert np.array_equal(mine, nz.argsort(dim=-1, stable=True).numpy())
+        for r in range(a.shape[0]):
+            if len(np.unique(a[r])) == a.shape[1]:
+                assert np.array_equal(mine[r], ref[r])
+            else:
+                saw_tie = True
+                assert np.array_equal(a[r][mine[r]], a[r][ref[r]])
+                assert np.array_equal(np.sort(ref[r]), np.arange(a.shape[1]))
+    assert saw_tie, "fixtures are expected to contain crafted tied rows"
+    masked, unmasked, nm_img, nm_tac = O.mask_indices([n.numpy() for n in noises], cfg.ratio, cfg.n_img, cfg.n_tac, cfg.num_tactiles)
+    assert masked.dtype == np.int64 and unmasked.dtype == np.int64
+    # counts: reference shapes (decoder gathers)
+    assert masked.shape[1] == z["cap/to_pixels_in"].shape[1] + z["cap/to_tactiles_in"].shape[1]
+    assert unmasked.shape[1] == z["cap/encoder_in"].shape[1]
+    both = np.sort(np.concatenate([masked, unmasked], 1), 1)
+    assert np.array_equal(both, np.broadcast_to(np.arange(cfg.n_total), both.shape))
+
+
+def test_mask_counts_python_double_semantics():
+    # r=.95, N=192 -> 182 masked, 60 image, 61 per tactile
+    assert O.mask_counts(0.95, 64, 128, 2) == (182, 60, 61)
+    assert O.mask_counts(0.75, 64, 128, 2) == (144, 48, 48)
+    assert O.mask_counts(0.75, 64, 0, 0) == (48, 48, 0)
+    assert O.mask_counts(0.75, 196, 256, 4) == (339, 147, 48)
+    assert O.mask_counts(0.8, 25, 50, 2) == (60, 20, 20)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_intermediates_and_loss(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    P = O.load_fixture_params(z)
+    x, noises = _inputs(z)
+    perms = [z[f"argsort/{i}"] for i in range(len(noises))]     # the permutations of THIS reference run
+    with torch.no_grad():
+        r = O.vtmae_forward(P, cfg, x, noises, perms=perms)
+        r_stable = O.vtmae_forward(P, cfg, x, noises)
+    # tie order only permutes rows inside the masked lists here -> the loss must not depend on it
+    assert abs(float(r_stable["loss"]) - float(r["loss"])) <= 1e-6 * abs(float(r["loss"]))
+    tol = dict(rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(r["encoder_in"].numpy(), z["cap/encoder_in"], **tol)
+    np.testing.assert_allclose(r["encoder_out"].numpy(), z["cap/encoder_out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["decoder_in"].numpy(), z["cap/decoder_in"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["decoder_out"].numpy(), z["cap/decoder_out"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(r["pred_pixel"].numpy(), z["cap/to_pixels_out"], rtol=1e-4, atol=2e-5)
+    if cfg.num_tactiles:
+        np.testing.assert_allclose(r["pred_tactile"].numpy(), z["cap/to_tactiles_out"], rtol=1e-4, atol=2e-5)
+    assert abs(float(r["loss"]) - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_backward_grads(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    P = O.load_fixture_params(z, requires_grad=True)
+    x, noises = _inputs(z)
+    O.vtmae_forward(P, cfg, x, noises)["loss"].backward()
+    unused = set(str(u) for u in z["unused_params"])
+    checked = 0
+    for k in z.files:
+        if not k.startswith("grad/"):
+            continue
+        name_ = k[len("grad/"):]
+        g = P[name_].grad
+        assert g is not None, name_
+        ref = z[k]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        assert float(np.abs(g.numpy() - ref).max()) <= 2e-4 * scale + 1e-7, name_
+        checked += 1
+    assert checked > 20
+    # parameters the reference leaves without grad (sincos mode) must also be unused in the restatement
+    for u in unused:
+        assert P[u].grad is None, u
+
+
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim"])
+def test_get_embeddings(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    P = O.load_fixture_params(z)
+    x, _ = _inputs(z)
+    with torch.no_grad():
+        e = O.get_embeddings(P, cfg, x)
+    np.testing.assert_allclose(e.numpy(), z["embeddings"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("fs", [1, 2])
+def test_vt_load(golden_dir, fs):
+    z = _load(golden_dir, f"vt_load_fs{fs}")
+    out = O.vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, frame_stack=fs)
+    assert sorted(out.keys()) == sorted(k[4:] for k in z.files if k.startswith("out/"))
+    for k, v in out.items():
+        assert v.dtype == torch.float32
+        np.testing.assert_array_equal(v.numpy(), z["out/" + k])
+
+
+def test_sincos_buffers_match_reference_buffers(golden_dir):
+    z = _load(golden_dir, "vt_decdim")     # D=128, dd=64: decoder code = first dd channels of the D-parameterised code
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    g = cfg.image_hw // cfg.image_patch
+    np.testing.assert_allclose(O.sincos_2d(cfg.dim, g, g, cfg.dim).numpy(), z["param/image_enc_pos_embedding"][0], atol=1e-6)
+    np.testing.assert_allclose(O.sincos_2d(cfg.dim, g, g, cfg.dec_dim).numpy(), z["param/image_dec_pos_embedding"][0], atol=1e-6)
+    gt = cfg.tactile_hw // cfg.tactile_patch
+    tac = O.sincos_2d(cfg.dim, gt, gt, cfg.dim).repeat(cfg.num_tactiles, 1)
+    np.testing.assert_allclose(tac.numpy(), z["param/tactile_enc_pos_embedding"][0], atol=1e-6)
+
+
+def test_dino_style_vtt(golden_dir):
+    z = _load(golden_dir, "vtt_dino_small")
+    hw, p, D, depth, heads, mlp, B = [int(v) for v in z["meta"]]
+    P = O.load_fixture_params(z)
+    x = {k[len("input/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("input/")}
+    np.testing.assert_allclose(O.sinusoidal_embed((3 * hw // p, hw // p), D).numpy(), z["pos_embed"], atol=1e-6)
+    masks = [torch.tensor(z["mask/0"]), torch.tensor(z["mask/1"])]
+    np.testing.assert_array_equal(O.apply_masks(torch.tensor(z["apply_masks/in"]), masks).numpy(), z["apply_masks/out"])
+    with torch.no_grad():
+        full = O.vtt_dino_forward(P, image_patch=p, tactile_patch=p, depth=depth, heads=heads, x=x)
+        mk = O.vtt_dino_forward(P, image_patch=p, tactile_patch=p, depth=depth, heads=heads, x=x, masks=masks)
+    np.testing.assert_allclose(full["x_prenorm"].numpy(), z["full/x_prenorm"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(full["x_norm_patchtokens"].numpy(), z["full/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(mk["x_norm_patchtokens"].numpy(), z["masked/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)

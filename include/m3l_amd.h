@@ -1,0 +1,126 @@
+/* m3l_amd — C ABI of the MI355X-native masked multimodal auto-encoder (MAE) training step.
+ *
+ * The reference (Leonhard111/M3L) is pure Python: its "FFI" for this path is the nn.Module object graph
+ * (models/pretrain_models.py:59-786).  This header is the boundary a binding would load instead: plain pointers
+ * and sizes, no torch types.  Every entry point
+ *   - is asynchronous on the given hipStream_t (pass torch.cuda.current_stream().cuda_stream),
+ *   - allocates nothing (the caller passes workspaces sized by the *_ws_bytes functions),
+ *   - returns 0 on success, non-zero on error (text via m3l_last_error; nothing is thrown across the ABI),
+ *   - takes device pointers unless a parameter says "host".
+ * dtype codes: 0 = f32 compute (parity path), 1 = bf16 compute (fp32 master weights, fp32 accumulation,
+ * fp32 residual stream).  dim_head is 64 everywhere (all reference configs).
+ *
+ * Reference interface each entry replaces:
+ *   m3l_mask_sample        torch.rand(B,n).argsort(-1) per modality + slicing      pretrain_models.py:223-248
+ *   m3l_embed_fwd/bwd      Rearrange + LayerNorm/Linear/LayerNorm + modality + sincos + visible gather
+ *                                                                                   pretrain_models.py:157-216,255-256,768-778
+ *   m3l_transformer_*      vit_pytorch.vit.Transformer.forward (encoder :266, decoder :309, extractor :836)
+ *   m3l_unshuffle_*        enc_to_dec + zeros/scatter/mask_token + decoder modality/sincos   :270-307
+ *   m3l_heads_loss_*       masked-row gather + to_pixels/to_tactiles + F.mse_loss (x1 / x10)   :260-262,327-340
+ *   m3l_layernorm_*        nn.LayerNorm (models/VTT.py:354 final norm of the DINO-style encoder)
+ *   m3l_vt_load            utils/pretrain_utils.py:7-57 (NHWC -> NCHW, per-sensor channel pick, [-1,1] -> [0,1])
+ */
+#ifndef M3L_AMD_H
+#define M3L_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3L_MAX_TACTILES 8
+
+typedef struct m3l_geom {
+    int image_h, image_w, image_patch, image_channels;
+    int tactile_h, tactile_w, tactile_patch, tactile_channels;
+    int num_tactiles;        /* sensors in the model */
+    int use_vision;          /* 0 -> image tokens absent from this call */
+    int use_tactile;         /* 0 -> tactile tokens absent from this call */
+} m3l_geom;
+
+typedef struct m3l_tf_cfg {
+    int dim, depth, heads, mlp_dim;
+    int project_out;         /* vit_pytorch: to_out is Identity when heads == 1 and dim_head == dim */
+    int dtype;
+} m3l_tf_cfg;
+
+int m3l_version(void);
+int m3l_last_error(char* buf, size_t n);
+
+/* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
+ * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.
+ * counts_host (out, host): [num_masked, num_unmasked, nm_img, nm_tac, n_img, n_tac] */
+int m3l_mask_counts(const m3l_geom* g, double ratio, int* counts_host);
+int m3l_mask_sample(const m3l_geom* g, double ratio, int B, const float* const* noise, int64_t* masked, int64_t* unmasked,
+                    void* stream);
+
+/* ---- patch embed.  idx == NULL: all patches (get_embeddings); else idx = unmasked (B, L) and only those rows are embedded.
+ * cnt_img = number of image entries at the head of each list row (n_img when idx == NULL, n_img - nm_img for the visible list).
+ * tensors: image {ln1_w, ln1_b, W[D,pd], b, ln2_w, ln2_b}, tactile {same 6}, mod_emb[(1+k),D], pos_img[n_img,D], pos_tac[k*n_tac,D]
+ * tokens out: f32 (B, L, D).  grads: same order as tensors (entries 12..14: mod_emb grad, NULL, NULL). */
+size_t m3l_embed_ws_bytes(const m3l_geom* g, int D, int dtype, int B, int L);
+int m3l_embed_fwd(const m3l_geom* g, int D, int dtype, int B, int L, int cnt_img, const int64_t* idx, const float* image,
+                  const float* const* tactiles, const void* const* tensors, void* ws, float* tokens, void* stream);
+int m3l_embed_bwd(const m3l_geom* g, int D, int dtype, int B, int L, int cnt_img, const int64_t* idx, const float* image,
+                  const float* const* tactiles, const void* const* tensors, void* ws, const float* dtokens, float* const* grads,
+                  void* stream);
+
+/* ---- transformer stack.  x_in f32 (B, n, D).  tensors: per layer {ln1_w, ln1_b, qkv_w[3HD,D], out_w[D,HD], out_b, ln2_w, ln2_b,
+ * fc1_w[mlp,D], fc1_b, fc2_w[D,mlp], fc2_b} x depth, then {norm_w, norm_b}.  Outputs: y_t (compute type, may be NULL) and
+ * y32 (f32, may be NULL) = final LayerNorm output.  ws keeps the activations for the backward. */
+size_t m3l_transformer_ws_bytes(const m3l_tf_cfg* c, int B, int n);
+int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, void* y_t,
+                        float* y32, void* stream);
+/* dy_dtype: 0 -> dy is f32, 1 -> dy is bf16 (must equal c->dtype when 1).  dx_in out: f32 (B, n, D) or NULL. */
+int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
+                        int dy_dtype, float* dx_in, float* const* grads, void* stream);
+
+/* ---- encoder -> decoder glue.  enc32 / enc_t: final-norm output of the encoder (B, nvis, D) in f32 / compute type.
+ * tensors: {e2d_w[dd,D] or NULL, e2d_b or NULL, mask_token[dd], dec_mod[(1+k),dd], pos_img_dec[n_img,dd], pos_tac_dec[k*n_tac,dd]} */
+size_t m3l_unshuffle_ws_bytes(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask);
+int m3l_unshuffle_fwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask, const int64_t* unmasked,
+                      const int64_t* masked, const float* enc32, const void* enc_t, const void* const* tensors, void* ws,
+                      float* dec_in, void* stream);
+/* d_enc out: gradient w.r.t. the encoder output; f32 when e2d is NULL (then *d_enc_dtype = 0) else compute type (= dtype). */
+int m3l_unshuffle_bwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask, const int64_t* unmasked,
+                      const int64_t* masked, const void* enc_t, const void* const* tensors, void* ws, const float* d_dec_in,
+                      void* d_enc, int* d_enc_dtype, float* const* grads, void* stream);
+
+/* ---- heads + masked MSE.  dec_t: decoder output (B, N, dd) compute type.  tensors: {pix_w[pd_i,dd], pix_b, tac_w[pd_t,dd], tac_b}.
+ * loss out: f32 scalar = mse(img) + 10 mse(tac).  Optional dumps (f32, may be NULL): pred/target of each head. */
+size_t m3l_heads_ws_bytes(const m3l_geom* g, int dd, int dtype, int B, int nmask);
+int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                       const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
+                       float* loss, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream);
+/* d_dec out: compute type (B, N, dd), zero on visible rows.  dloss: device f32 scalar (upstream gradient) or NULL for 1. */
+int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                       const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream);
+
+/* ---- stand-alone ops (also used by the DINO-style VTT front end and by the unit tests) */
+size_t m3l_layernorm_ws_bytes(int D);
+int m3l_layernorm_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y,
+                      float* y32, void* stream);
+int m3l_layernorm_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
+                      float* dx, void* ws, float* dgamma, float* dbeta, void* stream);
+/* rows of src (B, N, D) f32 picked by idx (B, K) -> dst (B, K, D)  [tactile_ssl.utils.apply_masks] and its scatter-add-free adjoint */
+int m3l_gather_tokens(const float* src, int B, int N, int D, const int64_t* idx, int K, float* dst, void* stream);
+int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx, int K, float* dst_zeroed, void* stream);
+/* obs (B, H, W, 3*fs) f32 NHWC -> image (B, 3*fs, H, W); tactile (B, 3*S*fs, h, w) -> per-sensor (B, 3*fs, h, w), (x+1)/2 */
+int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
+                int n_sensors, int frame_stack, float* const* tactile_out, void* stream);
+
+/* ---- raw kernels, exported for the per-kernel parity tests */
+int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                   const float* res, float* out_f32, void* out_t, void* out_pre, const void* gelu_u, int act, int ldc, void* stream);
+size_t m3l_op_gemm_tn_ws_bytes(int M, int N, int K);
+int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, void* ws, size_t ws_bytes,
+                   float* out, int ldo, void* stream);
+int m3l_op_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, void* stream);
+int m3l_op_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B,
+                    int n, int H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

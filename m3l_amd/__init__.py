@@ -1,0 +1,7 @@
+"""m3l_amd — MI355X-native (gfx950, hand-written HIP) masked multimodal auto-encoder training step: a drop-in for the
+VTT / VTMAE representation path of Leonhard111/M3L (models/pretrain_models.py, models/VTT.py) and nothing else."""
+from ._lib import LIB_PATH, M3LError  # noqa: F401
+from .pretrain_models import VTMAE, VTT, Transformer  # noqa: F401
+from .pretrain_utils import vt_load  # noqa: F401
+
+__all__ = ["VTT", "VTMAE", "Transformer", "vt_load", "M3LError", "LIB_PATH"]

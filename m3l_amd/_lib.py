@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI in include/m3l_amd.h (libm3l_amd.so, hand-written HIP for gfx950).
+
+The product path has NO CPU / PyTorch fallback: if the shared library is missing this module raises at first use.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libm3l_amd.so")
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_sz = C.c_size_t
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, c_i) for n in ("image_h", "image_w", "image_patch", "image_channels", "tactile_h", "tactile_w",
+                                   "tactile_patch", "tactile_channels", "num_tactiles", "use_vision", "use_tactile")]
+
+
+class TfCfg(C.Structure):
+    _fields_ = [(n, c_i) for n in ("dim", "depth", "heads", "mlp_dim", "project_out", "dtype")]
+
+
+_SIGS = {
+    "m3l_version": (c_i, []),
+    "m3l_last_error": (c_i, [C.c_char_p, c_sz]),
+    "m3l_mask_counts": (c_i, [C.POINTER(Geom), C.c_double, C.POINTER(c_i)]),
+    "m3l_mask_sample": (c_i, [C.POINTER(Geom), C.c_double, c_i, c_p, c_p, c_p, c_p]),
+    "m3l_embed_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i]),
+    "m3l_embed_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_embed_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_transformer_ws_bytes": (c_sz, [C.POINTER(TfCfg), c_i, c_i]),
+    "m3l_transformer_fwd": (c_i, [C.POINTER(TfCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_transformer_bwd": (c_i, [C.POINTER(TfCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "m3l_unshuffle_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i]),
+    "m3l_unshuffle_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_unshuffle_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                C.POINTER(c_i), c_p, c_p]),
+    "m3l_heads_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i]),
+    "m3l_heads_loss_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                 c_p, c_p, c_p]),
+    "m3l_heads_loss_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_layernorm_ws_bytes": (c_sz, [c_i]),
+    "m3l_layernorm_fwd": (c_i, [c_i, c_p, c_i, c_i, c_p, c_p, C.c_float, c_p, c_p, c_p]),
+    "m3l_layernorm_bwd": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, C.c_float, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_gather_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "m3l_scatter_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "m3l_vt_load": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "m3l_op_gemm_nt": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "m3l_op_gemm_tn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "m3l_op_gemm_tn": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p, c_i, c_p]),
+    "m3l_op_attn_fwd": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "m3l_op_attn_bwd": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+_lib = None
+
+
+class M3LError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built — there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M3LError(
+                f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+                "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, --offload-arch=gfx950). "
+                "m3l_amd has no CPU / eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().m3l_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise M3LError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """void*[] of device pointers (host array handed to the C side)."""
+    arr = (c_p * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr

@@ -1,0 +1,153 @@
+// Shared device-side building blocks for the gfx950 (MI355X / CDNA4) kernels of m3l_amd.
+//
+// One abstraction carries every matrix product in this library, for both compute types:
+//
+//   Frag<T>   = the 8 k-elements one lane feeds to a 16x16 MFMA "macro step" of depth 32
+//               T = bf16 : one v_mfma_f32_16x16x32_bf16   (lane (i = lane&15, g = lane>>4) holds k = kmap(g, j))
+//               T = float: eight v_mfma_f32_16x16x4_f32   (sub-step j uses element j of every lane; exact f32)
+//   A k-map says which k index element j of lane-group g stands for.  Both operands of a product must use
+//   the same map; the sum over k does not care about the order:
+//     KMAP_NAT : k = 8 g + j                      (what a 16-byte k-contiguous read delivers)
+//     KMAP_ACC : k = 4 g + (j & 3) + 16 (j >> 2)  (what two stacked 16x16 accumulator tiles hold per lane,
+//                                                  MI355X guide "An accumulator tile as the next MFMA's operand")
+//   Accumulator (C/D) layout of a 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.
+//
+//   load_kc : operand whose k index is CONTIGUOUS in LDS (row = i, 8 consecutive k)  -> ds_read_b128
+//   load_ks : operand whose k index is the ROW index of a row-major LDS tile (k-strided)
+//             bf16 -> two ds_read_b64_tr_b16 (hardware transpose read), f32 -> eight ds_read_b32
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define M3L_WAVE 64
+
+enum { KMAP_NAT = 0, KMAP_ACC = 1 };
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+
+// D = A * B + C for one 16x16 tile over a macro step of 32 k.
+__device__ __forceinline__ f32x4 mma16(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+}
+
+// k-contiguous operand: p -> 8 consecutive k elements of this lane's row (16-byte aligned).
+__device__ __forceinline__ Frag<bf16> load_kc(const bf16* p) {
+    Frag<bf16> f;
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+    return f;
+}
+__device__ __forceinline__ Frag<float> load_kc(const float* p) {
+    Frag<float> f;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    return f;
+}
+
+// k-strided operand from a row-major LDS tile `t` (row = k, leading dimension ld elements).
+// Delivers, for lane (i = lane & 15, g = lane >> 4): element j = t[(k0 + kmap(g, j)) * ld + c0 + i].
+// bf16: ds_read_b64_tr_b16 — within each 16-lane group, lane 4q+p supplies the address of block row q,
+// columns 4p..4p+3, and lane i receives column i of the 4 rows (guide T10).  EXEC must be all ones.
+template <int KMAP>
+__device__ __forceinline__ Frag<bf16> load_ks(const bf16* t, int ld, int k0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = (KMAP == KMAP_NAT) ? (k0 + 8 * g + q) : (k0 + 4 * g + q);
+    const int r1 = (KMAP == KMAP_NAT) ? (r0 + 4) : (r0 + 16);
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(t + r0 * ld + c0 + 4 * p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(t + r1 * ld + c0 + 4 * p));
+    Frag<bf16> f;
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+    return f;
+}
+template <int KMAP>
+__device__ __forceinline__ Frag<float> load_ks(const float* t, int ld, int k0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = (KMAP == KMAP_NAT) ? (8 * g + j) : (4 * g + (j & 3) + 16 * (j >> 2));
+        f.v[j] = t[(k0 + k) * ld + c0 + i];
+    }
+    return f;
+}
+
+// Two stacked accumulator tiles (rows 0..15 and 16..31 of a 32-deep k range) -> operand fragment (KMAP_ACC).
+template <typename T> __device__ __forceinline__ Frag<T> acc_to_frag(f32x4 t0, f32x4 t1);
+template <> __device__ __forceinline__ Frag<bf16> acc_to_frag<bf16>(f32x4 t0, f32x4 t1) {
+    Frag<bf16> f;
+    f.v[0] = (bf16)t0[0]; f.v[1] = (bf16)t0[1]; f.v[2] = (bf16)t0[2]; f.v[3] = (bf16)t0[3];
+    f.v[4] = (bf16)t1[0]; f.v[5] = (bf16)t1[1]; f.v[6] = (bf16)t1[2]; f.v[7] = (bf16)t1[3];
+    return f;
+}
+template <> __device__ __forceinline__ Frag<float> acc_to_frag<float>(f32x4 t0, f32x4 t1) {
+    Frag<float> f;
+    f.v[0] = t0[0]; f.v[1] = t0[1]; f.v[2] = t0[2]; f.v[3] = t0[3];
+    f.v[4] = t1[0]; f.v[5] = t1[1]; f.v[6] = t1[2]; f.v[7] = t1[3];
+    return f;
+}
+
+// 16-byte global <-> register chunk of T (8 bf16 or 4 floats)
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16> { static constexpr int N = 8; };
+template <> struct Chunk<float> { static constexpr int N = 4; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+void m3l_set_error(const char* fmt, ...);
+#define M3L_CHECK(cond, ...)                 \
+    do {                                     \
+        if (!(cond)) {                       \
+            m3l_set_error(__VA_ARGS__);      \
+            return 1;                        \
+        }                                    \
+    } while (0)
+#define M3L_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            m3l_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)
+#define M3L_LAUNCH_CHECK() M3L_HIP(hipGetLastError())
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,822 @@
+// HBM-bound kernels of the M3L MAE path (gfx950): LayerNorm fwd/bwd, patchify + gather + LayerNorm (patch embed
+// front end), embed finalisation (+modality +sincos), random-mask rank sort, decoder un-shuffle scatter, masked-row
+// gather/scatter, masked-patch MSE, column sums for bias gradients, weight down-cast/transposition.
+// One wavefront (64 lanes) owns one row; all cross-lane reductions are wave reductions, all parameter-gradient
+// reductions over rows go through per-workgroup partial slabs + a fixed-order reduce (bitwise reproducible).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXV = 16;          // elements per lane: rows up to 1024 wide
+constexpr int WPB = 4;            // waves (rows) per 256-thread block
+
+__device__ __forceinline__ void store_val(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_val(bf16* p, float v) { *p = (bf16)v; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta    (nn.LayerNorm, biased variance)
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, TO* __restrict__ y,
+                                                       float* __restrict__ y32) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * D;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = (e < D) ? xr[e] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        const float d = (e < D) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < D) {
+            const float r = (v[i] - mean) * rstd * gamma[e] + beta[e];
+            if (y) store_val(y + (long)row * D + e, r);
+            if (y32) y32[(long)row * D + e] = r;
+        }
+    }
+}
+
+// LayerNorm backward.  dx_out = (dres ? dres : 0) + dLN/dx ; per-block partial dgamma/dbeta -> part[G][2*D].
+template <typename TD>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, int M, int D,
+                                                       const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
+                                                       float* __restrict__ dx_out, float* __restrict__ part) {
+    __shared__ float red[WPB][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) dg[i] = db[i] = 0.f;
+    for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
+        const float* xr = x + (long)row * D;
+        const TD* dyr = dy + (long)row * D;
+        float v[MAXV], gdy[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            v[i] = (e < D) ? xr[e] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            const float d = (e < D) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < D) {
+                const float xh = (v[i] - mean) * rstd;
+                const float d = to_f32(dyr[e]);
+                dg[i] += d * xh;
+                db[i] += d;
+                const float gd = d * gamma[e];
+                gdy[i] = gd;
+                v[i] = xh;
+                s1 += gd;
+                s2 += gd * xh;
+            } else {
+                gdy[i] = 0.f;
+                v[i] = 0.f;
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+        if (dx_out) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int e = lane + 64 * i;
+                if (e < D) {
+                    float r = rstd * (gdy[i] - s1 - v[i] * s2);
+                    if (dres) r += dres[(long)row * D + e];
+                    dx_out[(long)row * D + e] = r;
+                }
+            }
+        }
+    }
+    // reduce the 4 waves' register partials through LDS in a fixed order, 64 columns at a time
+    float* out = part + (long)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (64 * i >= D) break;                 // uniform
+        red[wave][lane] = dg[i];
+        red[wave][64 + lane] = db[i];
+        __syncthreads();
+        if (wave == 0) {
+            const int e = lane + 64 * i;
+            if (e < D) {
+                out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                out[D + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[j] = (accumulate ? out[j] : 0) + sum_g part[g*stride + j],  j < count   (fixed summation order)
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int G, int stride, int count, float* __restrict__ out,
+                                   int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(long)g * stride + j];
+    out[j] = accumulate ? out[j] + s : s;
+}
+
+// column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, rows strided by grid
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int M, int N, int ld, int rows_per_block,
+                                                       float* __restrict__ part) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += to_f32(Y[(long)r * ld + c]);
+        part[(long)blockIdx.x * N + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights: fp32 master -> compute-type copy (zero-padded leading dim) + transposed copy (for dgrad as an NT GEMM)
+template <typename T>
+__global__ void prep_weights_kernel(WeightPack pack) {
+    const WeightDesc d = pack.d[blockIdx.y];
+    const long total = (long)d.rows * d.cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d.cols), c = (int)(i % d.cols);
+        const float v = d.src[i];
+        if (d.dst) reinterpret_cast<T*>(d.dst)[(long)r * d.ld_dst + c] = from_f32<T>(v);
+        if (d.dstT) reinterpret_cast<T*>(d.dstT)[(long)c * d.ld_dstT + r] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void axpy_t_kernel(const float* __restrict__ x, const T* __restrict__ o, long count, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = x[i] + to_f32(o[i]);
+}
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ x, long count, T* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = from_f32<T>(x[i]);
+}
+
+template <typename T>
+__global__ void scale_by_dev_kernel(const T* __restrict__ x, long count, const float* __restrict__ s, T* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = from_f32<T>(to_f32(x[i]) * s[0]);
+}
+
+// vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW (normalisation [0,1] is the identity);
+// tactile (B, 3*S*fs, h, w): sensor s takes channels {f*3S + 3s + c}, value (x + 1) / 2
+__global__ void vt_image_kernel(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C * H * W) return;
+    const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((long)W * H)) % C), b = (int)(i / ((long)W * H * C));
+    out[i] = in[(((long)b * H + h) * W + w) * C + c];
+}
+struct VtTactileOut { float* p[M3L_MAX_SENSORS]; };
+__global__ void vt_tactile_kernel(const float* __restrict__ in, int B, int th, int tw, int S, int fs, VtTactileOut o) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CH = 3 * S * fs;
+    if (i >= (long)B * CH * th * tw) return;
+    const int px = (int)(i % ((long)th * tw)), ch = (int)((i / ((long)th * tw)) % CH), b = (int)(i / ((long)th * tw * CH));
+    const int f = ch / (3 * S), r = ch % (3 * S), s = r / 3, c = r % 3;
+    o.p[s][(((long)b * 3 * fs) + f * 3 + c) * th * tw + px] = (in[i] + 1.0f) * 0.5f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// random-mask sampling: per (sample, modality) row of noise -> STABLE ascending rank -> masked / unmasked lists
+// (reference: torch.rand(B, n).argsort(-1), models/pretrain_models.py:229-248; tie-break = ascending index)
+__global__ void mask_rank_kernel(const float* __restrict__ noise, int n, int nm, int token_offset, int64_t* __restrict__ masked,
+                                 int masked_ld, int masked_off, int64_t* __restrict__ unmasked, int unmasked_ld, int unmasked_off) {
+    extern __shared__ float keys[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = noise[(long)b * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float k = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float o = keys[j];
+            rank += (o < k) || (o == k && j < i);
+        }
+        const int64_t tok = (int64_t)(i + token_offset);
+        if (rank < nm)
+            masked[(long)b * masked_ld + masked_off + rank] = tok;
+        else
+            unmasked[(long)b * unmasked_ld + unmasked_off + rank - nm] = tok;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch front end.  Row r = b*cnt + jj of a modality group; its token is idx[b*idx_ld + j0 + jj] (or base + jj when
+// idx == nullptr: all patches).  local = token - base, sensor s = local / npatch, patch = local % npatch.
+// patch element e = (p1*P + p2)*C + c  <->  src[s][b, c, ph*P + p1, pw*P + p2]   (einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)')
+__device__ __forceinline__ void patch_locate(const PatchGroup& pg, const int64_t* idx, int idx_ld, int j0, int cnt, int row,
+                                             int& b, int& s, int& ph, int& pw, int& local) {
+    b = row / cnt;
+    const int jj = row % cnt;
+    const int tok = idx ? (int)idx[(long)b * idx_ld + j0 + jj] : pg.base + jj;
+    local = tok - pg.base;
+    s = local / pg.npatch;
+    const int pidx = local % pg.npatch;
+    const int gw = pg.W / pg.P;
+    ph = pidx / gw;
+    pw = pidx % gw;
+}
+__device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, int ph, int pw, int e) {
+    const int c = e % pg.C, p2 = (e / pg.C) % pg.P, p1 = e / (pg.C * pg.P);
+    return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
+}
+
+// gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
+                                                         int rows, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, T* __restrict__ xn, int pdpad) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int pd = pg.C * pg.P * pg.P;
+    int b, s, ph, pw, local;
+    patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+    float v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / pd;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        const float d = (e < pd) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / pd + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < pd)
+            xn[(long)row * pdpad + e] = from_f32<T>((v[i] - mean) * rstd * gamma[e] + beta[e]);
+        else if (e < pdpad)
+            xn[(long)row * pdpad + e] = from_f32<T>(0.f);
+    }
+}
+
+// backward of the first patch LayerNorm w.r.t. its affine parameters (the input is data): part[G][2*pd]
+template <typename T>
+__global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
+                                                             int rows, float eps, const T* __restrict__ dxn, int pdpad,
+                                                             float* __restrict__ part) {
+    __shared__ float red[WPB][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pd = pg.C * pg.P * pg.P;
+    float dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) dg[i] = db[i] = 0.f;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        int b, s, ph, pw, local;
+        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+        float v[MAXV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
+            sum += v[i];
+        }
+        const float mean = wave_sum(sum) / pd;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            const float d = (e < pd) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / pd + eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < pd) {
+                const float d = to_f32(dxn[(long)row * pdpad + e]);
+                dg[i] += d * (v[i] - mean) * rstd;
+                db[i] += d;
+            }
+        }
+    }
+    float* out = part + (long)blockIdx.x * 2 * pd;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (64 * i >= pd) break;
+        red[wave][lane] = dg[i];
+        red[wave][64 + lane] = db[i];
+        __syncthreads();
+        if (wave == 0) {
+            const int e = lane + 64 * i;
+            if (e < pd) {
+                out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                out[pd + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// second patch LayerNorm + modality embedding + fixed sincos position -> tokens[b, j0 + jj, :]  (f32 residual stream)
+__global__ __launch_bounds__(256) void embed_finalize_kernel(const float* __restrict__ E, int rows, int D, PatchGroup pg,
+                                                               const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, const float* __restrict__ mod, int mod0,
+                                                               const float* __restrict__ pos, float* __restrict__ tokens, int L) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int b, s, ph, pw, local;
+    patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+    const float* xr = E + (long)row * D;
+    float v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = (e < D) ? xr[e] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        const float d = (e < D) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    const int jj = row % cnt;
+    float* out = tokens + ((long)b * L + j0 + jj) * D;
+    const float* mrow = mod + (long)(mod0 + s) * D;
+    const float* prow = pos + (long)local * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < D) out[e] = (v[i] - mean) * rstd * gamma[e] + beta[e] + mrow[e] + prow[e];
+    }
+}
+
+// backward of embed_finalize: dE (compute type) + partials [G][(2 + nslot) * D]: dgamma | dbeta | dmod[slot]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_finalize_bwd_kernel(const float* __restrict__ dtok, int L, const float* __restrict__ E,
+                                                                   int rows, int D, PatchGroup pg, const int64_t* __restrict__ idx,
+                                                                   int idx_ld, int j0, int cnt, const float* __restrict__ gamma,
+                                                                   float eps, T* __restrict__ dE, float* __restrict__ part, int nslot) {
+    extern __shared__ float sm[];   // [WPB][(2 + nslot) * D]: one private slab per wave (no atomics -> fixed order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int PL = (2 + nslot) * D;
+    for (int i = threadIdx.x; i < WPB * PL; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    float* my = sm + wave * PL;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        int b, s, ph, pw, local;
+        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+        const int jj = row % cnt;
+        const float* xr = E + (long)row * D;
+        const float* dyr = dtok + ((long)b * L + j0 + jj) * D;
+        float v[MAXV], gdy[MAXV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            v[i] = (e < D) ? xr[e] : 0.f;
+            sum += v[i];
+        }
+        const float mean = wave_sum(sum) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            const float d = (e < D) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < D) {
+                const float xh = (v[i] - mean) * rstd;
+                const float d = dyr[e];
+                my[e] += d * xh;                           // element e is always owned by lane e % 64 of this wave
+                my[D + e] += d;
+                my[(2 + s) * D + e] += d;
+                const float gd = d * gamma[e];
+                gdy[i] = gd;
+                v[i] = xh;
+                s1 += gd;
+                s2 += gd * xh;
+            } else {
+                gdy[i] = 0.f;
+                v[i] = 0.f;
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < D) dE[(long)row * D + e] = from_f32<T>(rstd * (gdy[i] - s1 - v[i] * s2));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PL; i += 256)
+        part[(long)blockIdx.x * PL + i] = sm[i] + sm[PL + i] + sm[2 * PL + i] + sm[3 * PL + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder un-shuffle (pretrain_models.py:279-307): dec_in[b, pos] = (visible ? src[b, j] : mask_token) + dmod[m(pos)] + dpos[pos]
+__global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float* __restrict__ src, const float* __restrict__ mask_token,
+                                                              const int64_t* __restrict__ unmasked, int nvis,
+                                                              const int64_t* __restrict__ masked, int nmask, int B, int dd,
+                                                              int n_img, int n_tac, const float* __restrict__ dmod,
+                                                              const float* __restrict__ pos_img, const float* __restrict__ pos_tac,
+                                                              float* __restrict__ dec_in) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int N = nvis + nmask;
+    if (r >= (long)B * N) return;
+    const int b = (int)(r / N), j = (int)(r % N);
+    const bool vis = j < nvis;
+    const int pos = (int)(vis ? unmasked[(long)b * nvis + j] : masked[(long)b * nmask + j - nvis]);
+    const float* s = vis ? src + ((long)b * nvis + j) * dd : mask_token;
+    const int m = pos < n_img ? 0 : 1 + (pos - n_img) / n_tac;
+    const float* prow = pos < n_img ? pos_img + (long)pos * dd : pos_tac + (long)(pos - n_img) * dd;
+    float* out = dec_in + ((long)b * N + pos) * dd;
+    for (int e = lane; e < dd; e += 64) out[e] = s[e] + dmod[(long)m * dd + e] + prow[e];
+}
+
+// backward: dsrc[b, j] = d_dec_in[b, unmasked[b, j]] ; partials [G][(1 + nmod) * dd]: dmask_token | ddmod[m]
+__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ dY, const int64_t* __restrict__ unmasked,
+                                                              int nvis, const int64_t* __restrict__ masked, int nmask, int B, int dd,
+                                                              int n_img, int n_tac, int nmod, float* __restrict__ dsrc,
+                                                              float* __restrict__ part) {
+    extern __shared__ float sm[];   // [WPB][(1 + nmod) * dd]: one private slab per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int PL = (1 + nmod) * dd;
+    const int N = nvis + nmask;
+    for (int i = threadIdx.x; i < WPB * PL; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    float* my = sm + wave * PL;
+    for (long r = (long)blockIdx.x * WPB + wave; r < (long)B * N; r += (long)gridDim.x * WPB) {
+        const int b = (int)(r / N), j = (int)(r % N);
+        const bool vis = j < nvis;
+        const int pos = (int)(vis ? unmasked[(long)b * nvis + j] : masked[(long)b * nmask + j - nvis]);
+        const int m = pos < n_img ? 0 : 1 + (pos - n_img) / n_tac;
+        const float* g = dY + ((long)b * N + pos) * dd;
+        for (int e = lane; e < dd; e += 64) {
+            const float d = g[e];
+            if (vis)
+                dsrc[((long)b * nvis + j) * dd + e] = d;
+            else
+                my[e] += d;
+            my[(1 + m) * dd + e] += d;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PL; i += 256)
+        part[(long)blockIdx.x * PL + i] = sm[i] + sm[PL + i] + sm[2 * PL + i] + sm[3 * PL + i];
+}
+
+// rows of src [B, N, D] selected by idx[b, j0 + jj] -> dst [B*cnt, D]
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, int N, int D, const int64_t* __restrict__ idx,
+                                                            int idx_ld, int j0, int cnt, int rows, T* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / cnt, jj = row % cnt;
+    const long pos = idx[(long)b * idx_ld + j0 + jj];
+    const T* s = src + ((long)b * N + pos) * D;
+    T* d = dst + (long)row * D;
+    for (int e = lane; e < D; e += 64) d[e] = s[e];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__ src, int N, int D, const int64_t* __restrict__ idx,
+                                                             int idx_ld, int j0, int cnt, int rows, T* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / cnt, jj = row % cnt;
+    const long pos = idx[(long)b * idx_ld + j0 + jj];
+    const T* s = src + (long)row * D;
+    T* d = dst + ((long)b * N + pos) * D;
+    for (int e = lane; e < D; e += 64) d[e] = s[e];
+}
+
+// masked-patch MSE (pretrain_models.py:260-262,327-340): pred [rows, pdpad] f32 vs raw target patches gathered by the
+// masked indices; part[G] = w * sum (pred - tgt)^2 ; dpred = 2 w (pred - tgt) in compute type (pad columns zero)
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, int pdpad, PatchGroup pg,
+                                                    const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt, int rows, float w,
+                                                    float* __restrict__ part, T* __restrict__ dpred, float* __restrict__ target_out) {
+    __shared__ float red[WPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pd = pg.C * pg.P * pg.P;
+    float acc = 0.f;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        int b, s, ph, pw, local;
+        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+        for (int e = lane; e < pdpad; e += 64) {
+            float d = 0.f;
+            if (e < pd) {
+                const float t = patch_elem(pg, b, s, ph, pw, e);
+                d = pred[(long)row * pdpad + e] - t;
+                if (target_out) target_out[(long)row * pd + e] = t;
+            }
+            acc += d * d;
+            dpred[(long)row * pdpad + e] = from_f32<T>(2.f * w * d);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = w * (red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+// =================================================================================================================
+static int ln_grid(int M) { return cdiv(M, WPB); }
+static int part_grid(long rows) {
+    long g = (rows + WPB - 1) / WPB;
+    if (g > M3L_MAX_PARTIAL_BLOCKS) g = M3L_MAX_PARTIAL_BLOCKS;
+    return (int)(g < 1 ? 1 : g);
+}
+
+int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y, float* y32,
+               hipStream_t st) {
+    M3L_CHECK(M > 0 && D > 0 && D <= 64 * MAXV, "ln_fwd: bad shape M=%d D=%d", M, D);
+    if (out_dtype == 1)
+        ln_fwd_kernel<bf16><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (bf16*)y, y32);
+    else
+        ln_fwd_kernel<float><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (float*)y, y32);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st) {
+    reduce_rows_kernel<<<cdiv(count, 256), 256, 0, st>>>(part, G, stride, count, out, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
+               float* dx_out, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+    M3L_CHECK(M > 0 && D > 0 && D <= 64 * MAXV, "ln_bwd: bad shape M=%d D=%d", M, D);
+    const int G = part_grid(M);
+    if (dy_dtype == 1)
+        ln_bwd_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)dy, x, M, D, gamma, eps, dres, dx_out, part_ws);
+    else
+        ln_bwd_kernel<float><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, part_ws);
+    M3L_LAUNCH_CHECK();
+    // part rows are [dgamma(D) | dbeta(D)]; dgamma and dbeta live in different tensors
+    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws, G, 2 * D, D, dgamma, accumulate);
+    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws + D, G, 2 * D, D, dbeta, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st) {
+    M3L_CHECK(M > 0 && N > 0, "colsum: bad shape");
+    int G = cdiv(M, 64);
+    if (G > M3L_MAX_PARTIAL_BLOCKS) G = M3L_MAX_PARTIAL_BLOCKS;
+    const int rpb = cdiv(M, G);
+    G = cdiv(M, rpb);
+    if (dtype == 1)
+        colsum_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)Y, M, N, ld, rpb, part_ws);
+    else
+        colsum_kernel<float><<<G, 256, 0, st>>>((const float*)Y, M, N, ld, rpb, part_ws);
+    M3L_LAUNCH_CHECK();
+    return m3l_reduce_rows(part_ws, G, N, N, out, accumulate, st);
+}
+
+int m3l_prep_weights(int dtype, const WeightPack* pack, hipStream_t st) {
+    if (pack->count <= 0) return 0;
+    dim3 grid(64, pack->count);
+    if (dtype == 1)
+        prep_weights_kernel<bf16><<<grid, 256, 0, st>>>(*pack);
+    else
+        prep_weights_kernel<float><<<grid, 256, 0, st>>>(*pack);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st) {
+    if (dtype == 1)
+        axpy_t_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>(x, (const bf16*)o, count, out);
+    else
+        axpy_t_kernel<float><<<cdiv(count, 256), 256, 0, st>>>(x, (const float*)o, count, out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st) {
+    if (dtype == 1)
+        cast_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>(x, count, (bf16*)out);
+    else
+        cast_kernel<float><<<cdiv(count, 256), 256, 0, st>>>(x, count, (float*)out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st) {
+    if (dtype == 1)
+        scale_by_dev_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>((const bf16*)x, count, scale_dev, (bf16*)out);
+    else
+        scale_by_dev_kernel<float><<<cdiv(count, 256), 256, 0, st>>>((const float*)x, count, scale_dev, (float*)out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_vt_load_launch(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
+                       int n_sensors, int frame_stack, float* const* tactile_out, hipStream_t st) {
+    if (image_nhwc) {
+        const long total = (long)B * C * H * W;
+        vt_image_kernel<<<cdiv(total, 256), 256, 0, st>>>(image_nhwc, B, H, W, C, image_nchw);
+        M3L_LAUNCH_CHECK();
+    }
+    if (tactile) {
+        M3L_CHECK(n_sensors >= 1 && n_sensors <= M3L_MAX_SENSORS, "vt_load: n_sensors=%d", n_sensors);
+        VtTactileOut o;
+        for (int s = 0; s < n_sensors; ++s) o.p[s] = tactile_out[s];
+        const long total = (long)B * 3 * n_sensors * frame_stack * th * tw;
+        vt_tactile_kernel<<<cdiv(total, 256), 256, 0, st>>>(tactile, B, th, tw, n_sensors, frame_stack, o);
+        M3L_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
+                  int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st) {
+    M3L_CHECK(B > 0 && n > 0 && nm >= 0 && nm <= n, "mask_rank: bad shape B=%d n=%d nm=%d", B, n, nm);
+    M3L_CHECK(n <= 8192, "mask_rank: n=%d too large", n);
+    const int threads = n <= 64 ? 64 : (n <= 128 ? 128 : 256);
+    mask_rank_kernel<<<B, threads, n * sizeof(float), st>>>(noise, n, nm, token_offset, masked, masked_ld, masked_off, unmasked,
+                                                            unmasked_ld, unmasked_off);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_pg(const PatchGroup& pg) {
+    const int pd = pg.C * pg.P * pg.P;
+    M3L_CHECK(pg.nsrc >= 1 && pg.nsrc <= M3L_MAX_SENSORS, "patch group: nsrc=%d", pg.nsrc);
+    M3L_CHECK(pd <= 64 * MAXV, "patch dim %d > %d unsupported", pd, 64 * MAXV);
+    M3L_CHECK(pg.H % pg.P == 0 && pg.W % pg.P == 0, "image dims must be divisible by the patch size");
+    return 0;
+}
+
+int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, const float* gamma,
+                 const float* beta, float eps, void* xn, int pdpad, hipStream_t st) {
+    if (check_pg(*pg)) return 1;
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    if (dtype == 1)
+        patch_ln_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (bf16*)xn, pdpad);
+    else
+        patch_ln_kernel<float><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (float*)xn, pdpad);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, float eps,
+                     const void* dxn, int pdpad, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+    if (check_pg(*pg)) return 1;
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    const int pd = pg->C * pg->P * pg->P;
+    const int G = part_grid(rows);
+    if (dtype == 1)
+        patch_ln_bwd_kernel<bf16><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const bf16*)dxn, pdpad, part_ws);
+    else
+        patch_ln_bwd_kernel<float><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const float*)dxn, pdpad, part_ws);
+    M3L_LAUNCH_CHECK();
+    reduce_rows_kernel<<<cdiv(pd, 256), 256, 0, st>>>(part_ws, G, 2 * pd, pd, dgamma, accumulate);
+    reduce_rows_kernel<<<cdiv(pd, 256), 256, 0, st>>>(part_ws + pd, G, 2 * pd, pd, dbeta, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_embed_finalize(const float* E, int D, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B,
+                       const float* gamma, const float* beta, float eps, const float* mod, int mod0, const float* pos,
+                       float* tokens, int L, hipStream_t st) {
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    M3L_CHECK(D <= 64 * MAXV, "embed_finalize: D=%d too large", D);
+    embed_finalize_kernel<<<ln_grid(rows), 256, 0, st>>>(E, rows, D, *pg, idx, idx_ld, j0, cnt, gamma, beta, eps, mod, mod0, pos, tokens, L);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_embed_finalize_bwd(int dtype, const float* dtok, int L, const float* E, int D, const PatchGroup* pg, const int64_t* idx,
+                           int idx_ld, int j0, int cnt, int B, const float* gamma, float eps, void* dE, float* part_ws,
+                           float* dgamma, float* dbeta, float* dmod, int mod0, int accumulate, hipStream_t st) {
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    const int nslot = pg->nsrc;
+    const int PL = (2 + nslot) * D;
+    const int G = part_grid(rows);
+    if (dtype == 1)
+        embed_finalize_bwd_kernel<bf16><<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, L, E, rows, D, *pg, idx, idx_ld, j0, cnt, gamma, eps, (bf16*)dE, part_ws, nslot);
+    else
+        embed_finalize_bwd_kernel<float><<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, L, E, rows, D, *pg, idx, idx_ld, j0, cnt, gamma, eps, (float*)dE, part_ws, nslot);
+    M3L_LAUNCH_CHECK();
+    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws, G, PL, D, dgamma, accumulate);
+    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws + D, G, PL, D, dbeta, accumulate);
+    reduce_rows_kernel<<<cdiv(nslot * D, 256), 256, 0, st>>>(part_ws + 2 * D, G, PL, nslot * D, dmod + (long)mod0 * D, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int k_unshuffle_fwd(const float* src, const float* mask_token, const int64_t* unmasked, int nvis, const int64_t* masked,
+                      int nmask, int B, int dd, int n_img, int n_tac, const float* dmod, const float* pos_img, const float* pos_tac,
+                      float* dec_in, hipStream_t st) {
+    const long rows = (long)B * (nvis + nmask);
+    unshuffle_fwd_kernel<<<cdiv(rows, WPB), 256, 0, st>>>(src, mask_token, unmasked, nvis, masked, nmask, B, dd, n_img,
+                                                           n_tac > 0 ? n_tac : 1, dmod, pos_img, pos_tac, dec_in);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const int64_t* masked, int nmask, int B, int dd, int n_img,
+                      int n_tac, int nmod, float* dsrc, float* part_ws, float* dmask_token, float* ddmod, int accumulate,
+                      hipStream_t st) {
+    const long rows = (long)B * (nvis + nmask);
+    const int PL = (1 + nmod) * dd;
+    const int G = part_grid(rows);
+    unshuffle_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dY, unmasked, nvis, masked, nmask, B, dd, n_img, n_tac > 0 ? n_tac : 1,
+                                                             nmod, dsrc, part_ws);
+    M3L_LAUNCH_CHECK();
+    reduce_rows_kernel<<<cdiv(dd, 256), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
+    reduce_rows_kernel<<<cdiv(nmod * dd, 256), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_gather_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
+                    hipStream_t st) {
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    if (dtype == 1)
+        gather_rows_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>((const bf16*)src, N, D, idx, idx_ld, j0, cnt, rows, (bf16*)dst);
+    else
+        gather_rows_kernel<float><<<ln_grid(rows), 256, 0, st>>>((const float*)src, N, D, idx, idx_ld, j0, cnt, rows, (float*)dst);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_scatter_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
+                     hipStream_t st) {
+    const int rows = B * cnt;
+    if (rows == 0) return 0;
+    if (dtype == 1)
+        scatter_rows_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>((const bf16*)src, N, D, idx, idx_ld, j0, cnt, rows, (bf16*)dst);
+    else
+        scatter_rows_kernel<float><<<ln_grid(rows), 256, 0, st>>>((const float*)src, N, D, idx, idx_ld, j0, cnt, rows, (float*)dst);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_mse(int dtype, const float* pred, int pdpad, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B,
+            float weight, float* part_ws, int* nblocks_out, void* dpred, float* target_out, hipStream_t st) {
+    if (check_pg(*pg)) return 1;
+    const int rows = B * cnt;
+    if (nblocks_out) *nblocks_out = 0;
+    if (rows == 0) return 0;
+    const int pd = pg->C * pg->P * pg->P;
+    const float w = weight / ((float)rows * (float)pd);
+    const int G = part_grid(rows);
+    if (dtype == 1)
+        mse_kernel<bf16><<<G, 256, 0, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (bf16*)dpred, target_out);
+    else
+        mse_kernel<float><<<G, 256, 0, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (float*)dpred, target_out);
+    M3L_LAUNCH_CHECK();
+    if (nblocks_out) *nblocks_out = G;
+    return 0;
+}

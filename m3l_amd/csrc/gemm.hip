@@ -1,0 +1,313 @@
+// MFMA GEMMs of the M3L MAE path for gfx950 (wave64, v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32).
+//
+//   gemm_nt : C[M,N] = A[M,K] * W[N,K]^T  (+bias, GELU, gelu'(u) multiply, f32 residual) — every nn.Linear
+//             forward of the path (reference: vit_pytorch Attention.to_qkv / to_out, FeedForward.net[1],[4];
+//             models/pretrain_models.py:111,115,116,770,777) and, with the pre-transposed weight copy, every dgrad.
+//   gemm_tn : dW[N,K] = sum_m Y[m,N]^T X[m,K]   (weight gradients), split over m with deterministic f32 slabs.
+//
+// Tile: 128 x 128 per 256-thread workgroup (2x2 waves of 64x64 = 4x4 MFMA tiles), register-staged double-buffered
+// LDS (global_load_dwordx4 issued before the MFMA block, ds_write after it: guide T14), epilogue staged through LDS
+// so that every global store is a 16-byte row segment.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T> struct NtCfg;
+template <> struct NtCfg<bf16> { static constexpr int BK = 64, KSTEPS = 2, ROW = 72; };    // 144-byte padded LDS rows
+template <> struct NtCfg<float> { static constexpr int BK = 32, KSTEPS = 1, ROW = 36; };
+
+constexpr int NT_STAGE_BYTES = 128 * 144;           // one operand tile
+constexpr int NT_LDS_BYTES = 4 * NT_STAGE_BYTES;    // A,B x 2 stages = 73,728 B ; epilogue tile 128*132*4 = 67,584 B fits
+constexpr int CS_LD = 132;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                        int M, int N, int K, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = NtCfg<T>;
+    constexpr int EPC = Chunk<T>::N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    auto As = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st) * NT_STAGE_BYTES); };
+    auto Bs = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st + 1) * NT_STAGE_BYTES); };
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+            const int k = k0 + cc * EPC;
+            const uint4 z = {0u, 0u, 0u, 0u};
+            ra[i] = (m0 + row < M && k < K) ? *reinterpret_cast<const uint4*>(A + (long)(m0 + row) * lda + k) : z;
+            rb[i] = (n0 + row < N && k < K) ? *reinterpret_cast<const uint4*>(W + (long)(n0 + row) * ldw + k) : z;
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(As(st)) + row * 144 + cc * 16) = ra[i];
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Bs(st)) + row * 144 + cc * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + C::BK - 1) / C::BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) gload((t + 1) * C::BK);
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            Frag<T> fa[4], fb[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                fa[x] = load_kc(As(cur) + (wr * 64 + x * 16 + li) * C::ROW + ks * 32 + g * 8);
+                fb[x] = load_kc(Bs(cur) + (wc * 64 + x * 16 + li) * C::ROW + ks * 32 + g * 8);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+        }
+        if (t + 1 < nk) swrite(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte row segments ---------------------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wr * 64 + a * 16 + 4 * g + r) * CS_LD + wc * 64 + b * 16 + li] = acc[a][b][r];
+    __syncthreads();
+
+    const int cchunk = tid & 15, r0 = tid >> 4;
+    const int col = n0 + cchunk * 8;
+    if (col >= N) return;
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias[j] = (epi.bias && col + j < epi.n_bias) ? epi.bias[col + j] : 0.f;
+    T* out_t = reinterpret_cast<T*>(epi.out_t);
+    T* out_pre = reinterpret_cast<T*>(epi.out_pre);
+    const T* gelu_u = reinterpret_cast<const T*>(epi.gelu_u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = r0 + 16 * i, row = m0 + rl;
+        if (row >= M) continue;
+        float v[8];
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(Cs + rl * CS_LD + cchunk * 8);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(Cs + rl * CS_LD + cchunk * 8 + 4);
+        v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3];
+        v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
+        const long o = (long)row * epi.ldc + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * epi.alpha + bias[j];
+        if (gelu_u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(to_f32(gelu_u[o + j]));
+        }
+        if (out_pre) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const T u = from_f32<T>(v[j]);
+                out_pre[o + j] = u;
+                v[j] = to_f32(u);
+            }
+        }
+        if (epi.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
+        if (epi.res) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += epi.res[o + j];
+        }
+        if (epi.out_f32) {
+            *reinterpret_cast<f32x4*>(epi.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(epi.out_f32 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (out_t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out_t[o + j] = from_f32<T>(v[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16> { static constexpr int BMT = 64, MS = 2, ROW = 144, CPR = 16; };   // 288-byte rows
+template <> struct TnCfg<float> { static constexpr int BMT = 32, MS = 1, ROW = 132, CPR = 32; };  // 528-byte rows
+constexpr int TN_STAGE_BYTES = 18432;               // max(64*288, 32*528)
+constexpr int TN_LDS_BYTES = 4 * TN_STAGE_BYTES;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, int ldy, const T* __restrict__ X, int ldx,
+                                                        int M, int N, int K, int m_per_split, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = TnCfg<T>;
+    constexpr int EPC = Chunk<T>::N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, sp = blockIdx.z;
+    const int m_beg = sp * m_per_split;
+    const int m_end = min(M, m_beg + m_per_split);
+
+    auto Ys = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st) * TN_STAGE_BYTES); };
+    auto Xs = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st + 1) * TN_STAGE_BYTES); };
+
+    uint4 ry[4], rx[4];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c / C::CPR, cc = c % C::CPR;
+            const int m = mb + row;
+            const uint4 z = {0u, 0u, 0u, 0u};
+            ry[i] = (m < m_end && n0 + cc * EPC < N) ? *reinterpret_cast<const uint4*>(Y + (long)m * ldy + n0 + cc * EPC) : z;
+            rx[i] = (m < m_end && k0 + cc * EPC < K) ? *reinterpret_cast<const uint4*>(X + (long)m * ldx + k0 + cc * EPC) : z;
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c / C::CPR, cc = c % C::CPR;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Ys(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = ry[i];
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Xs(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = rx[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (m_end - m_beg + C::BMT - 1) / C::BMT;
+    if (nt > 0) {
+        gload(m_beg);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) gload(m_beg + (t + 1) * C::BMT);
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) {
+            Frag<T> fa[4], fb[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                fa[x] = load_ks<KMAP_ACC>(Ys(cur), C::ROW, ms * 32, wr * 64 + x * 16, lane);
+                fb[x] = load_ks<KMAP_ACC>(Xs(cur), C::ROW, ms * 32, wc * 64 + x * 16, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+        }
+        if (t + 1 < nt) swrite(cur ^ 1);
+        __syncthreads();
+    }
+    float* P = partial + (long)sp * N * K;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 64 + a * 16 + 4 * g + r, k = k0 + wc * 64 + b * 16 + li;
+                if (n < N && k < K) P[(long)n * K + k] = acc[a][b][r];
+            }
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ partial, int S, int N, int K, float* __restrict__ out, int ldo,
+                                     int nvalid, int kvalid, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    if (k >= kvalid || n >= nvalid) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += partial[(long)i * N * K + idx];
+    float* o = out + (long)n * ldo + k;
+    *o = accumulate ? (*o + s) : s;
+}
+
+}  // namespace
+
+static int g_gemm_inited = 0;
+int m3l_gemm_init() {
+    if (g_gemm_inited) return 0;
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    g_gemm_inited = 1;
+    return 0;
+}
+
+int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi* epi_in,
+                hipStream_t st) {
+    if (m3l_gemm_init()) return 2;
+    GemmEpi e = *epi_in;
+    if (e.n_bias <= 0) e.n_bias = N;
+    const GemmEpi* epi = &e;
+    M3L_CHECK(dtype == 0 || dtype == 1, "gemm_nt: bad dtype %d", dtype);
+    M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
+    M3L_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && epi->ldc % 8 == 0,
+              "gemm_nt: K,N,lda,ldw,ldc must be multiples of 8 (got K=%d N=%d lda=%d ldw=%d ldc=%d)", K, N, lda, ldw, epi->ldc);
+    dim3 grid(cdiv(N, BN), cdiv(M, BM));
+    if (dtype == 1)
+        gemm_nt_kernel<bf16><<<grid, 256, NT_LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+    else
+        gemm_nt_kernel<float><<<grid, 256, NT_LDS_BYTES, st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
+    const int tiles = cdiv(N, 128) * cdiv(K, 128);
+    int S = cdiv(768, tiles);                 // ~3 workgroups per CU over 256 CUs
+    const int max_s = cdiv(M, 256);           // at least 256 rows per split
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    if (splits_out) *splits_out = S;
+    return (size_t)S * N * K * sizeof(float);
+}
+
+int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws,
+                size_t ws_bytes, float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st) {
+    if (m3l_gemm_init()) return 2;
+    M3L_CHECK(dtype == 0 || dtype == 1, "gemm_tn: bad dtype %d", dtype);
+    M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem %d %d %d", M, N, K);
+    M3L_CHECK(K % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N,K,ldy,ldx must be multiples of 8");
+    int S;
+    const size_t need = m3l_gemm_tn_ws_bytes(M, N, K, &S);
+    M3L_CHECK(ws_bytes >= need, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need);
+    const int unit = (dtype == 1) ? 64 : 32;
+    int mps = cdiv(cdiv(M, S), unit) * unit;
+    S = cdiv(M, mps);
+    dim3 grid(cdiv(N, 128), cdiv(K, 128), S);
+    if (dtype == 1)
+        gemm_tn_kernel<bf16><<<grid, 256, TN_LDS_BYTES, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, partial_ws);
+    else
+        gemm_tn_kernel<float><<<grid, 256, TN_LDS_BYTES, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, partial_ws);
+    M3L_LAUNCH_CHECK();
+    const long cnt = (long)N * K;
+    reduce_splits_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(partial_ws, S, N, K, out, ldo, nvalid, kvalid, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}

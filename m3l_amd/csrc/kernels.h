@@ -1,0 +1,90 @@
+// Internal launcher interface shared by the kernel translation units and the MAE step plan (mae_plan.hip).
+// Every launcher is asynchronous on the given stream, allocates nothing, returns 0 on success and sets the
+// thread-local error string otherwise (m3l_last_error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define M3L_MAX_SENSORS 8
+#define M3L_MAX_PARTIAL_BLOCKS 512
+
+// dtype codes: 0 = f32, 1 = bf16
+
+struct GemmEpi {
+    const float* bias;     // [N] or null
+    const float* res;      // f32 [M, ldc] residual added last, or null
+    float* out_f32;        // f32 [M, ldc] or null
+    void* out_t;           // compute-type [M, ldc] or null (post-activation)
+    void* out_pre;         // compute-type [M, ldc] pre-activation copy or null
+    const void* gelu_u;    // compute-type [M, ldc]: multiply by gelu'(u) (dgrad through GELU) or null
+    int act;               // 0 none, 1 GELU(erf)
+    int ldc;
+    float alpha;
+    int n_bias;            // bias has n_bias valid entries (columns beyond read as 0); 0 -> N
+};
+
+struct WeightDesc {
+    const float* src;      // [rows, cols] fp32 master
+    void* dst;             // [rows, ld_dst]  compute-type copy (or null)
+    void* dstT;            // [cols, ld_dstT] transposed compute-type copy (or null)
+    int rows, cols, ld_dst, ld_dstT;
+};
+#define M3L_WPACK 8
+struct WeightPack {
+    WeightDesc d[M3L_WPACK];
+    int count;
+};
+
+struct PatchGroup {
+    const float* src[M3L_MAX_SENSORS];   // NCHW f32 inputs of the sensors of this modality group
+    int nsrc, C, H, W, P;
+    int npatch;                          // patches per sensor
+    int base;                            // token index of the group's first patch
+};
+
+int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi* epi, hipStream_t st);
+size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);
+int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws, size_t ws_bytes,
+                float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st);
+int m3l_gemm_init();
+
+int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
+int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
+                 int H, hipStream_t st);
+
+int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y, float* y32,
+               hipStream_t st);
+int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
+               float* dx_out, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st);
+int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st);
+int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
+int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
+int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
+int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
+int m3l_vt_load_launch(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
+                       int n_sensors, int frame_stack, float* const* tactile_out, hipStream_t st);
+int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
+                  int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st);
+int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, const float* gamma,
+                 const float* beta, float eps, void* xn, int pdpad, hipStream_t st);
+int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, float eps,
+                     const void* dxn, int pdpad, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+int m3l_embed_finalize(const float* E, int D, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B,
+                       const float* gamma, const float* beta, float eps, const float* mod, int mod0, const float* pos, float* tokens,
+                       int L, hipStream_t st);
+int m3l_embed_finalize_bwd(int dtype, const float* dtok, int L, const float* E, int D, const PatchGroup* pg, const int64_t* idx,
+                           int idx_ld, int j0, int cnt, int B, const float* gamma, float eps, void* dE, float* part_ws, float* dgamma,
+                           float* dbeta, float* dmod, int mod0, int accumulate, hipStream_t st);
+int k_unshuffle_fwd(const float* src, const float* mask_token, const int64_t* unmasked, int nvis, const int64_t* masked, int nmask,
+                      int B, int dd, int n_img, int n_tac, const float* dmod, const float* pos_img, const float* pos_tac, float* dec_in,
+                      hipStream_t st);
+int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const int64_t* masked, int nmask, int B, int dd, int n_img,
+                      int n_tac, int nmod, float* dsrc, float* part_ws, float* dmask_token, float* ddmod, int accumulate, hipStream_t st);
+int m3l_gather_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
+                    hipStream_t st);
+int m3l_scatter_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
+                     hipStream_t st);
+int m3l_mse(int dtype, const float* pred, int pdpad, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B,
+            float weight, float* part_ws, int* nblocks_out, void* dpred, float* target_out, hipStream_t st);

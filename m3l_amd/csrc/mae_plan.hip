@@ -1,0 +1,675 @@
+// Host-side runtime of the MI355X-native MAE step: the C ABI of include/m3l_amd.h.
+// Each entry point lays its activations out in the caller's workspace (bump arena, 256-byte aligned) and issues the
+// kernel sequence of one module (patch embed / transformer stack / un-shuffle / heads+loss), forward or backward, on
+// the caller's HIP stream.  No allocation, no synchronisation, no host<->device copies: safe to capture in a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/m3l_amd.h"
+#include "common.cuh"
+#include "kernels.h"
+
+static thread_local char g_err[512] = {0};
+void m3l_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(void* b) : base(reinterpret_cast<char*>(b)) {}
+    void* take(size_t bytes) {
+        off = (off + 255) & ~size_t(255);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    template <typename T> T* take_n(size_t n) { return reinterpret_cast<T*>(take(n * sizeof(T))); }
+};
+
+inline int pad8(int x) { return (x + 7) & ~7; }
+inline size_t esz(int dtype) { return dtype ? 2 : 4; }
+
+// scratch big enough for every reduction / split-K slab of one module
+size_t scratch_bytes(int M, const std::vector<std::pair<int, int>>& wshapes, int maxcols) {
+    size_t s = (size_t)M3L_MAX_PARTIAL_BLOCKS * 4 * (size_t)maxcols * sizeof(float);
+    for (auto& nk : wshapes) s = std::max(s, m3l_gemm_tn_ws_bytes(M, nk.first, nk.second, nullptr));
+    return s;
+}
+
+GemmEpi epi0(int ldc) {
+    GemmEpi e;
+    memset(&e, 0, sizeof(e));
+    e.ldc = ldc;
+    e.alpha = 1.f;
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// geometry helpers
+struct Geo {
+    int n_img, n_tac, k;              // active counts (0 when the modality is absent from the call)
+    int pd_img, pd_tac, pdp_img, pdp_tac;
+};
+Geo geo_of(const m3l_geom* g) {
+    Geo o;
+    o.n_img = g->use_vision ? (g->image_h / g->image_patch) * (g->image_w / g->image_patch) : 0;
+    o.k = (g->use_tactile && g->num_tactiles > 0) ? g->num_tactiles : 0;
+    o.n_tac = o.k ? (g->tactile_h / g->tactile_patch) * (g->tactile_w / g->tactile_patch) : 0;
+    o.pd_img = g->image_channels * g->image_patch * g->image_patch;
+    o.pd_tac = g->tactile_channels * g->tactile_patch * g->tactile_patch;
+    o.pdp_img = pad8(o.pd_img);
+    o.pdp_tac = pad8(o.pd_tac);
+    return o;
+}
+PatchGroup group_img(const m3l_geom* g, const Geo& ge, const float* image) {
+    PatchGroup pg;
+    memset(&pg, 0, sizeof(pg));
+    pg.src[0] = image;
+    pg.nsrc = 1;
+    pg.C = g->image_channels; pg.H = g->image_h; pg.W = g->image_w; pg.P = g->image_patch;
+    pg.npatch = ge.n_img > 0 ? ge.n_img : 1;
+    pg.base = 0;
+    return pg;
+}
+PatchGroup group_tac(const m3l_geom* g, const Geo& ge, const float* const* tactiles) {
+    PatchGroup pg;
+    memset(&pg, 0, sizeof(pg));
+    for (int i = 0; i < ge.k; ++i) pg.src[i] = tactiles[i];
+    pg.nsrc = ge.k > 0 ? ge.k : 1;
+    pg.C = g->tactile_channels; pg.H = g->tactile_h; pg.W = g->tactile_w; pg.P = g->tactile_patch;
+    pg.npatch = ge.n_tac > 0 ? ge.n_tac : 1;
+    pg.base = ge.n_img;
+    return pg;
+}
+int check_geom(const m3l_geom* g) {
+    M3L_CHECK(g->num_tactiles >= 0 && g->num_tactiles <= M3L_MAX_TACTILES, "num_tactiles=%d out of range", g->num_tactiles);
+    M3L_CHECK(g->image_h % g->image_patch == 0 && g->image_w % g->image_patch == 0, "Image dimensions must be divisible by the patch size.");
+    M3L_CHECK(g->num_tactiles == 0 || (g->tactile_h % g->tactile_patch == 0 && g->tactile_w % g->tactile_patch == 0),
+              "Tactile dimensions must be divisible by the patch size.");
+    M3L_CHECK(g->use_vision || (g->use_tactile && g->num_tactiles > 0), "neither vision nor tactile tokens present");
+    return 0;
+}
+void mask_counts(const Geo& ge, double ratio, int* c) {
+    // pretrain_models.py:223-227 — Python double arithmetic with int() truncation
+    const int N = ge.n_img + ge.k * ge.n_tac;
+    const int num_masked = (int)(ratio * (double)N);
+    const double image_perc = (double)ge.n_img / (double)N;
+    const int nm_img = (int)((double)num_masked * image_perc);
+    const int nm_tac = ge.k > 0 ? (num_masked - nm_img) / ge.k : 0;
+    const int total_masked = nm_img + ge.k * nm_tac;
+    c[0] = total_masked; c[1] = N - total_masked; c[2] = nm_img; c[3] = nm_tac; c[4] = ge.n_img; c[5] = ge.n_tac;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// transformer stack
+struct TfLayer {
+    void *wqkv, *wqkvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
+    void *xn1, *qkv, *o, *xn2, *u, *h;
+    float *lse, *x1, *xout;
+};
+struct TfWs {
+    std::vector<TfLayer> L;
+    float* dx;
+    void *dx_t, *du, *dxn, *d_o, *dqkv;
+    float* dsum;
+    float* scratch;
+    size_t scratch_b;
+    size_t total;
+};
+TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
+    Arena a(ws);
+    const size_t M = (size_t)B * n, D = c->dim, HD = (size_t)c->heads * 64, mlp = c->mlp_dim, e = esz(c->dtype);
+    TfWs w;
+    w.L.resize(c->depth);
+    for (auto& l : w.L) {
+        l.wqkv = a.take(3 * HD * D * e); l.wqkvT = a.take(D * 3 * HD * e);
+        l.wo = a.take(D * HD * e);       l.woT = a.take(HD * D * e);
+        l.w1 = a.take(mlp * D * e);      l.w1T = a.take(D * mlp * e);
+        l.w2 = a.take(D * mlp * e);      l.w2T = a.take(mlp * D * e);
+        l.xn1 = a.take(M * D * e);
+        l.qkv = a.take(M * 3 * HD * e);
+        l.o = a.take(M * HD * e);
+        l.lse = a.take_n<float>((size_t)B * c->heads * n);
+        l.x1 = a.take_n<float>(M * D);
+        l.xn2 = a.take(M * D * e);
+        l.u = a.take(M * mlp * e);
+        l.h = a.take(M * mlp * e);
+        l.xout = a.take_n<float>(M * D);
+    }
+    w.dx = a.take_n<float>(M * D);
+    w.dx_t = a.take(M * D * e);
+    w.du = a.take(M * mlp * e);
+    w.dxn = a.take(M * D * e);
+    w.d_o = a.take(M * HD * e);
+    w.dqkv = a.take(M * 3 * HD * e);
+    w.dsum = a.take_n<float>((size_t)B * c->heads * n);
+    std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
+    w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
+    w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.total = a.off + 256;
+    return w;
+}
+int check_tf(const m3l_tf_cfg* c, int B, int n) {
+    M3L_CHECK(c->dtype == 0 || c->dtype == 1, "transformer: bad dtype %d", c->dtype);
+    M3L_CHECK(c->dim > 0 && c->dim % 8 == 0 && c->dim <= 1024, "transformer: dim=%d must be a multiple of 8, <= 1024", c->dim);
+    M3L_CHECK(c->mlp_dim > 0 && c->mlp_dim % 8 == 0, "transformer: mlp_dim=%d must be a multiple of 8", c->mlp_dim);
+    M3L_CHECK(c->heads > 0 && c->depth >= 0, "transformer: heads=%d depth=%d", c->heads, c->depth);
+    M3L_CHECK(c->project_out || c->heads * 64 == c->dim, "transformer: identity to_out needs heads*64 == dim");
+    M3L_CHECK(B > 0 && n > 0, "transformer: empty input B=%d n=%d", B, n);
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================================
+extern "C" {
+
+int m3l_version(void) { return 100; }
+
+int m3l_last_error(char* buf, size_t n) {
+    if (buf && n) {
+        strncpy(buf, g_err, n - 1);
+        buf[n - 1] = 0;
+    }
+    return (int)strlen(g_err);
+}
+
+int m3l_mask_counts(const m3l_geom* g, double ratio, int* counts_host) {
+    if (check_geom(g)) return 1;
+    M3L_CHECK(ratio > 0.0 && ratio < 1.0, "masking ratio must be kept between 0 and 1");
+    mask_counts(geo_of(g), ratio, counts_host);
+    return 0;
+}
+
+int m3l_mask_sample(const m3l_geom* g, double ratio, int B, const float* const* noise, int64_t* masked, int64_t* unmasked,
+                    void* stream) {
+    if (check_geom(g)) return 1;
+    M3L_CHECK(ratio > 0.0 && ratio < 1.0, "masking ratio must be kept between 0 and 1");
+    hipStream_t st = (hipStream_t)stream;
+    const Geo ge = geo_of(g);
+    int c[6];
+    mask_counts(ge, ratio, c);
+    const int nmask = c[0], nvis = c[1], nm_img = c[2], nm_tac = c[3];
+    int ni = 0;
+    if (ge.n_img > 0) {
+        if (m3l_mask_rank(noise[ni++], B, ge.n_img, nm_img, 0, masked, nmask, 0, unmasked, nvis, 0, st)) return 1;
+    }
+    for (int s = 0; s < ge.k; ++s) {
+        if (m3l_mask_rank(noise[ni++], B, ge.n_tac, nm_tac, ge.n_img + s * ge.n_tac, masked, nmask, nm_img + s * nm_tac, unmasked, nvis,
+                          (ge.n_img - nm_img) + s * (ge.n_tac - nm_tac), st))
+            return 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch embed
+namespace {
+struct EmbGroupWs {
+    void *w, *wT, *xn, *dE, *dxn;
+    float* E;
+};
+struct EmbWs {
+    EmbGroupWs g[2];
+    float* scratch;
+    size_t scratch_b, total;
+};
+EmbWs emb_layout(const Geo& ge, int D, int dtype, int B, void* ws) {
+    Arena a(ws);
+    EmbWs w;
+    const size_t e = esz(dtype);
+    const int pdp[2] = {ge.pdp_img, ge.pdp_tac};
+    const int maxrows[2] = {B * ge.n_img, B * ge.k * ge.n_tac};   // capacity = all patches; a visible list uses a prefix
+    for (int i = 0; i < 2; ++i) {
+        w.g[i].w = a.take((size_t)D * pdp[i] * e);
+        w.g[i].wT = a.take((size_t)pdp[i] * D * e);
+        w.g[i].xn = a.take((size_t)maxrows[i] * pdp[i] * e);
+        w.g[i].E = a.take_n<float>((size_t)maxrows[i] * D);
+        w.g[i].dE = a.take((size_t)maxrows[i] * D * e);
+        w.g[i].dxn = a.take((size_t)maxrows[i] * pdp[i] * e);
+    }
+    const int Mmax = std::max(maxrows[0], maxrows[1]);
+    std::vector<std::pair<int, int>> shapes = {{D, ge.pdp_img}, {D, ge.pdp_tac}};
+    w.scratch_b = scratch_bytes(std::max(Mmax, 1), shapes, std::max(D * (2 + M3L_MAX_TACTILES), std::max(ge.pdp_img, ge.pdp_tac)));
+    w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.total = a.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t m3l_embed_ws_bytes(const m3l_geom* g, int D, int dtype, int B, int L) {
+    if (check_geom(g)) return 0;
+    const Geo ge = geo_of(g);
+    (void)L;
+    return emb_layout(ge, D, dtype, B, nullptr).total;
+}
+
+namespace {
+int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, int cnt_img, const int64_t* idx, const float* image,
+              const float* const* tactiles, const void* const* tensors, void* ws, float* tokens, const float* dtokens,
+              float* const* grads, hipStream_t st) {
+    if (check_geom(g)) return 1;
+    M3L_CHECK(D % 8 == 0 && D <= 1024, "embed: dim=%d must be a multiple of 8, <= 1024", D);
+    const Geo ge = geo_of(g);
+    EmbWs w = emb_layout(ge, D, dtype, B, ws);
+    M3L_CHECK(idx || L == ge.n_img + ge.k * ge.n_tac, "embed: L=%d must equal the number of patches when idx is NULL", L);
+    const int cnt[2] = {cnt_img, L - cnt_img};
+    const int j0[2] = {0, cnt_img};
+    M3L_CHECK(cnt[0] >= 0 && cnt[1] >= 0 && cnt[0] <= ge.n_img && cnt[1] <= ge.k * ge.n_tac, "embed: inconsistent list split %d/%d", cnt[0], cnt[1]);
+    const PatchGroup pgs[2] = {group_img(g, ge, image), group_tac(g, ge, tactiles)};
+    const int pd[2] = {ge.pd_img, ge.pd_tac}, pdp[2] = {ge.pdp_img, ge.pdp_tac};
+    const float* mod = (const float*)tensors[12];
+    const float* pos[2] = {(const float*)tensors[13], (const float*)tensors[14]};
+    const int mod0[2] = {0, 1};
+    for (int i = 0; i < 2; ++i) {
+        if (cnt[i] == 0) continue;
+        const int rows = B * cnt[i];
+        const void* const* t = tensors + 6 * i;
+        const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *W = (const float*)t[2], *bias = (const float*)t[3];
+        const float *ln2_w = (const float*)t[4], *ln2_b = (const float*)t[5];
+        if (!backward) {
+            // compute-type weight copies (zero-padded K) — pad columns must be zero
+            M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)D * pdp[i] * esz(dtype), st));
+            M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)pdp[i] * D * esz(dtype), st));
+            WeightPack pk;
+            memset(&pk, 0, sizeof(pk));
+            pk.d[0] = WeightDesc{W, w.g[i].w, w.g[i].wT, D, pd[i], pdp[i], D};
+            pk.count = 1;
+            if (m3l_prep_weights(dtype, &pk, st)) return 1;
+            if (m3l_patch_ln(dtype, &pgs[i], idx, L, j0[i], cnt[i], B, ln1_w, ln1_b, LN_EPS, w.g[i].xn, pdp[i], st)) return 1;
+            GemmEpi e = epi0(D);
+            e.bias = bias;
+            e.out_f32 = w.g[i].E;
+            if (m3l_gemm_nt(dtype, w.g[i].xn, pdp[i], w.g[i].w, pdp[i], rows, D, pdp[i], &e, st)) return 1;
+            if (m3l_embed_finalize(w.g[i].E, D, &pgs[i], idx, L, j0[i], cnt[i], B, ln2_w, ln2_b, LN_EPS, mod, mod0[i], pos[i], tokens, L, st))
+                return 1;
+        } else {
+            float* const* gr = grads + 6 * i;
+            if (m3l_embed_finalize_bwd(dtype, dtokens, L, w.g[i].E, D, &pgs[i], idx, L, j0[i], cnt[i], B, ln2_w, LN_EPS, w.g[i].dE,
+                                       w.scratch, gr[4], gr[5], grads[12], mod0[i], 0, st))
+                return 1;
+            if (m3l_gemm_tn(dtype, w.g[i].dE, D, w.g[i].xn, pdp[i], rows, D, pdp[i], w.scratch, w.scratch_b, gr[2], pd[i], D, pd[i], 0, st))
+                return 1;
+            if (m3l_colsum(dtype, w.g[i].dE, rows, D, D, w.scratch, gr[3], 0, st)) return 1;
+            GemmEpi e = epi0(pdp[i]);
+            e.out_t = w.g[i].dxn;
+            if (m3l_gemm_nt(dtype, w.g[i].dE, D, w.g[i].wT, D, rows, pdp[i], D, &e, st)) return 1;
+            if (m3l_patch_ln_bwd(dtype, &pgs[i], idx, L, j0[i], cnt[i], B, LN_EPS, w.g[i].dxn, pdp[i], w.scratch, gr[0], gr[1], 0, st))
+                return 1;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+int m3l_embed_fwd(const m3l_geom* g, int D, int dtype, int B, int L, int cnt_img, const int64_t* idx, const float* image,
+                  const float* const* tactiles, const void* const* tensors, void* ws, float* tokens, void* stream) {
+    return embed_run(false, g, D, dtype, B, L, cnt_img, idx, image, tactiles, tensors, ws, tokens, nullptr, nullptr, (hipStream_t)stream);
+}
+int m3l_embed_bwd(const m3l_geom* g, int D, int dtype, int B, int L, int cnt_img, const int64_t* idx, const float* image,
+                  const float* const* tactiles, const void* const* tensors, void* ws, const float* dtokens, float* const* grads,
+                  void* stream) {
+    return embed_run(true, g, D, dtype, B, L, cnt_img, idx, image, tactiles, tensors, ws, nullptr, dtokens, grads, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// transformer
+size_t m3l_transformer_ws_bytes(const m3l_tf_cfg* c, int B, int n) {
+    if (check_tf(c, B, n)) return 0;
+    return tf_layout(c, B, n, nullptr).total;
+}
+
+int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, void* y_t,
+                        float* y32, void* stream) {
+    if (check_tf(c, B, n)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    TfWs w = tf_layout(c, B, n, ws);
+    const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
+    const float* x = x_in;
+    for (int l = 0; l < c->depth; ++l) {
+        TfLayer& L = w.L[l];
+        const void* const* t = tensors + 11 * l;
+        const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *qkv_w = (const float*)t[2], *out_w = (const float*)t[3],
+                    *out_b = (const float*)t[4], *ln2_w = (const float*)t[5], *ln2_b = (const float*)t[6], *fc1_w = (const float*)t[7],
+                    *fc1_b = (const float*)t[8], *fc2_w = (const float*)t[9], *fc2_b = (const float*)t[10];
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.d[0] = WeightDesc{qkv_w, L.wqkv, L.wqkvT, 3 * HD, D, D, 3 * HD};
+        pk.d[1] = WeightDesc{fc1_w, L.w1, L.w1T, mlp, D, D, mlp};
+        pk.d[2] = WeightDesc{fc2_w, L.w2, L.w2T, D, mlp, mlp, D};
+        pk.count = 3;
+        if (c->project_out) pk.d[pk.count++] = WeightDesc{out_w, L.wo, L.woT, D, HD, HD, D};
+        if (m3l_prep_weights(dt, &pk, st)) return 1;
+
+        if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
+        GemmEpi e = epi0(3 * HD);
+        e.out_t = L.qkv;
+        if (m3l_gemm_nt(dt, L.xn1, D, L.wqkv, D, M, 3 * HD, D, &e, st)) return 1;
+        if (m3l_attn_fwd(dt, L.qkv, L.o, L.lse, B, n, c->heads, st)) return 1;
+        if (c->project_out) {
+            e = epi0(D);
+            e.bias = out_b; e.res = x; e.out_f32 = L.x1;
+            if (m3l_gemm_nt(dt, L.o, HD, L.wo, HD, M, D, HD, &e, st)) return 1;
+        } else {
+            if (m3l_axpy_t(dt, x, L.o, (long)M * D, L.x1, st)) return 1;
+        }
+        if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
+        e = epi0(mlp);
+        e.bias = fc1_b; e.act = 1; e.out_pre = L.u; e.out_t = L.h;
+        if (m3l_gemm_nt(dt, L.xn2, D, L.w1, D, M, mlp, D, &e, st)) return 1;
+        e = epi0(D);
+        e.bias = fc2_b; e.res = L.x1; e.out_f32 = L.xout;
+        if (m3l_gemm_nt(dt, L.h, mlp, L.w2, mlp, M, D, mlp, &e, st)) return 1;
+        x = L.xout;
+    }
+    const void* const* tf = tensors + 11 * c->depth;
+    return m3l_ln_fwd(dt, x, M, D, (const float*)tf[0], (const float*)tf[1], LN_EPS, y_t, y32, st);
+}
+
+int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
+                        int dy_dtype, float* dx_in, float* const* grads, void* stream) {
+    if (check_tf(c, B, n)) return 1;
+    M3L_CHECK(dy_dtype == 0 || dy_dtype == c->dtype, "transformer_bwd: dy dtype %d incompatible with compute dtype %d", dy_dtype, c->dtype);
+    hipStream_t st = (hipStream_t)stream;
+    TfWs w = tf_layout(c, B, n, ws);
+    const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
+    const float* x_last = c->depth ? w.L[c->depth - 1].xout : x_in;
+    const void* const* tf = tensors + 11 * c->depth;
+    float* const* gf = grads + 11 * c->depth;
+    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, w.scratch, gf[0], gf[1], 0, st)) return 1;
+    for (int l = c->depth - 1; l >= 0; --l) {
+        TfLayer& L = w.L[l];
+        const float* xl = l ? w.L[l - 1].xout : x_in;
+        const void* const* t = tensors + 11 * l;
+        float* const* g = grads + 11 * l;
+        // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
+        if (m3l_cast_f32(dt, w.dx, (long)M * D, w.dx_t, st)) return 1;
+        GemmEpi e = epi0(mlp);
+        e.out_t = w.du; e.gelu_u = L.u;
+        if (m3l_gemm_nt(dt, w.dx_t, D, L.w2T, D, M, mlp, D, &e, st)) return 1;                        // du = (dx W2) * gelu'(u)
+        if (m3l_gemm_tn(dt, w.dx_t, D, L.h, mlp, M, D, mlp, w.scratch, w.scratch_b, g[9], mlp, D, mlp, 0, st)) return 1;
+        if (m3l_colsum(0, w.dx, M, D, D, w.scratch, g[10], 0, st)) return 1;
+        e = epi0(D);
+        e.out_t = w.dxn;
+        if (m3l_gemm_nt(dt, w.du, mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                      // dxn2 = du W1
+        if (m3l_gemm_tn(dt, w.du, mlp, L.xn2, D, M, mlp, D, w.scratch, w.scratch_b, g[7], D, mlp, D, 0, st)) return 1;
+        if (m3l_colsum(dt, w.du, M, mlp, mlp, w.scratch, g[8], 0, st)) return 1;
+        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.scratch, g[5], g[6], 0, st)) return 1;   // dx1 (in place)
+        // ---- attention: x1 = x + to_out(attn(LN1(x)))
+        const void* d_o = w.dx_t;
+        if (m3l_cast_f32(dt, w.dx, (long)M * D, w.dx_t, st)) return 1;
+        if (c->project_out) {
+            e = epi0(HD);
+            e.out_t = w.d_o;
+            if (m3l_gemm_nt(dt, w.dx_t, D, L.woT, D, M, HD, D, &e, st)) return 1;                     // do = dx1 Wo
+            if (m3l_gemm_tn(dt, w.dx_t, D, L.o, HD, M, D, HD, w.scratch, w.scratch_b, g[3], HD, D, HD, 0, st)) return 1;
+            if (m3l_colsum(0, w.dx, M, D, D, w.scratch, g[4], 0, st)) return 1;
+            d_o = w.d_o;
+        }
+        if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv, B, n, c->heads, st)) return 1;
+        e = epi0(D);
+        e.out_t = w.dxn;
+        if (m3l_gemm_nt(dt, w.dqkv, 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;         // dxn1 = dqkv Wqkv
+        if (m3l_gemm_tn(dt, w.dqkv, 3 * HD, L.xn1, D, M, 3 * HD, D, w.scratch, w.scratch_b, g[2], D, 3 * HD, D, 0, st)) return 1;
+        float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
+        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, w.scratch, g[0], g[1], 0, st)) return 1;
+    }
+    if (c->depth == 0 && dx_in) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// encoder -> decoder glue
+namespace {
+struct UnWs {
+    void *w, *wT, *dsrc_t;
+    float *proj, *dsrc;
+    float* scratch;
+    size_t scratch_b, total;
+};
+UnWs un_layout(int D, int dd, int dtype, int B, int nvis, void* ws) {
+    Arena a(ws);
+    UnWs w;
+    const size_t e = esz(dtype), Mv = (size_t)B * nvis;
+    w.w = a.take((size_t)dd * D * e);
+    w.wT = a.take((size_t)D * dd * e);
+    w.proj = a.take_n<float>(Mv * dd);
+    w.dsrc = a.take_n<float>(Mv * dd);
+    w.dsrc_t = a.take(Mv * dd * e);
+    std::vector<std::pair<int, int>> shapes = {{dd, D}};
+    w.scratch_b = scratch_bytes((int)Mv, shapes, std::max(D, dd * (2 + M3L_MAX_TACTILES)));
+    w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.total = a.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t m3l_unshuffle_ws_bytes(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask) {
+    (void)g; (void)nmask;
+    return un_layout(D, dd, dtype, B, nvis, nullptr).total;
+}
+
+int m3l_unshuffle_fwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask, const int64_t* unmasked,
+                      const int64_t* masked, const float* enc32, const void* enc_t, const void* const* tensors, void* ws,
+                      float* dec_in, void* stream) {
+    if (check_geom(g)) return 1;
+    M3L_CHECK(dd % 8 == 0 && D % 8 == 0, "unshuffle: dims must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    const Geo ge = geo_of(g);
+    M3L_CHECK(nvis + nmask == ge.n_img + ge.k * ge.n_tac, "unshuffle: nvis + nmask = %d != number of patches", nvis + nmask);
+    UnWs w = un_layout(D, dd, dtype, B, nvis, ws);
+    const float* e2d_w = (const float*)tensors[0];
+    const float* src = enc32;
+    if (e2d_w) {
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.d[0] = WeightDesc{e2d_w, w.w, w.wT, dd, D, D, dd};
+        pk.count = 1;
+        if (m3l_prep_weights(dtype, &pk, st)) return 1;
+        GemmEpi e = epi0(dd);
+        e.bias = (const float*)tensors[1];
+        e.out_f32 = w.proj;
+        if (m3l_gemm_nt(dtype, enc_t, D, w.w, D, B * nvis, dd, D, &e, st)) return 1;
+        src = w.proj;
+    } else {
+        M3L_CHECK(D == dd, "unshuffle: enc_to_dec weight missing but encoder dim %d != decoder dim %d", D, dd);
+    }
+    return k_unshuffle_fwd(src, (const float*)tensors[2], unmasked, nvis, masked, nmask, B, dd, ge.n_img, ge.n_tac,
+                             (const float*)tensors[3], (const float*)tensors[4], (const float*)tensors[5], dec_in, st);
+}
+
+int m3l_unshuffle_bwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask, const int64_t* unmasked,
+                      const int64_t* masked, const void* enc_t, const void* const* tensors, void* ws, const float* d_dec_in,
+                      void* d_enc, int* d_enc_dtype, float* const* grads, void* stream) {
+    if (check_geom(g)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const Geo ge = geo_of(g);
+    UnWs w = un_layout(D, dd, dtype, B, nvis, ws);
+    const bool proj = tensors[0] != nullptr;
+    float* dsrc = proj ? w.dsrc : (float*)d_enc;
+    if (k_unshuffle_bwd(d_dec_in, unmasked, nvis, masked, nmask, B, dd, ge.n_img, ge.n_tac, 1 + ge.k, dsrc, w.scratch, grads[2],
+                          grads[3], 0, st))
+        return 1;
+    if (!proj) {
+        if (d_enc_dtype) *d_enc_dtype = 0;
+        return 0;
+    }
+    const int Mv = B * nvis;
+    if (m3l_cast_f32(dtype, w.dsrc, (long)Mv * dd, w.dsrc_t, st)) return 1;
+    if (m3l_gemm_tn(dtype, w.dsrc_t, dd, enc_t, D, Mv, dd, D, w.scratch, w.scratch_b, grads[0], D, dd, D, 0, st)) return 1;
+    if (m3l_colsum(0, w.dsrc, Mv, dd, dd, w.scratch, grads[1], 0, st)) return 1;
+    GemmEpi e = epi0(D);
+    e.out_t = d_enc;
+    if (m3l_gemm_nt(dtype, w.dsrc_t, dd, w.wT, dd, Mv, D, dd, &e, st)) return 1;
+    if (d_enc_dtype) *d_enc_dtype = dtype;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// heads + masked MSE
+namespace {
+struct HeadGroupWs {
+    void *w, *wT, *dg, *dpred, *dpred_s, *ddg;
+    float* pred;
+};
+struct HeadWs {
+    HeadGroupWs g[2];
+    float* loss_part;
+    float* scratch;
+    size_t scratch_b, total;
+};
+HeadWs head_layout(const Geo& ge, int dd, int dtype, int B, int nmask, void* ws) {
+    Arena a(ws);
+    HeadWs w;
+    const size_t e = esz(dtype);
+    const int pdp[2] = {ge.pdp_img, ge.pdp_tac};
+    const size_t rows = (size_t)B * nmask;      // capacity per group (each group uses a share)
+    for (int i = 0; i < 2; ++i) {
+        w.g[i].w = a.take((size_t)pdp[i] * dd * e);
+        w.g[i].wT = a.take((size_t)dd * pdp[i] * e);
+        w.g[i].dg = a.take(rows * dd * e);
+        w.g[i].pred = a.take_n<float>(rows * pdp[i]);
+        w.g[i].dpred = a.take(rows * pdp[i] * e);
+        w.g[i].dpred_s = a.take(rows * pdp[i] * e);
+        w.g[i].ddg = a.take(rows * dd * e);
+    }
+    w.loss_part = a.take_n<float>(2 * M3L_MAX_PARTIAL_BLOCKS);
+    std::vector<std::pair<int, int>> shapes = {{ge.pdp_img, dd}, {ge.pdp_tac, dd}};
+    w.scratch_b = scratch_bytes((int)std::max(rows, (size_t)1), shapes, std::max(dd, std::max(ge.pdp_img, ge.pdp_tac)));
+    w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.total = a.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t m3l_heads_ws_bytes(const m3l_geom* g, int dd, int dtype, int B, int nmask) {
+    if (check_geom(g)) return 0;
+    return head_layout(geo_of(g), dd, dtype, B, nmask, nullptr).total;
+}
+
+int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                       const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
+                       float* loss, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream) {
+    if (check_geom(g)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const Geo ge = geo_of(g);
+    HeadWs w = head_layout(ge, dd, dtype, B, nmask, ws);
+    const int cnt[2] = {nm_img, nmask - nm_img}, j0[2] = {0, nm_img};
+    const int pd[2] = {ge.pd_img, ge.pd_tac}, pdp[2] = {ge.pdp_img, ge.pdp_tac};
+    const float weight[2] = {1.f, 10.f};
+    const PatchGroup pgs[2] = {group_img(g, ge, image), group_tac(g, ge, tactiles)};
+    float* tgt[2] = {tgt_img, tgt_tac};
+    float* pred_out[2] = {pred_img, pred_tac};
+    int nparts = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (cnt[i] == 0) continue;
+        const int rows = B * cnt[i];
+        M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)pdp[i] * dd * esz(dtype), st));
+        M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)dd * pdp[i] * esz(dtype), st));
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.d[0] = WeightDesc{(const float*)tensors[2 * i], w.g[i].w, w.g[i].wT, pd[i], dd, dd, pdp[i]};
+        pk.count = 1;
+        if (m3l_prep_weights(dtype, &pk, st)) return 1;
+        if (m3l_gather_rows(dtype, dec_t, N, dd, masked, nmask, j0[i], cnt[i], B, w.g[i].dg, st)) return 1;
+        GemmEpi e = epi0(pdp[i]);
+        e.bias = (const float*)tensors[2 * i + 1];
+        e.n_bias = pd[i];
+        e.out_f32 = w.g[i].pred;
+        if (m3l_gemm_nt(dtype, w.g[i].dg, dd, w.g[i].w, dd, rows, pdp[i], dd, &e, st)) return 1;
+        int nb = 0;
+        if (m3l_mse(dtype, w.g[i].pred, pdp[i], &pgs[i], masked, nmask, j0[i], cnt[i], B, weight[i], w.loss_part + nparts, &nb,
+                    w.g[i].dpred, tgt[i], st))
+            return 1;
+        nparts += nb;
+        if (pred_out[i])
+            M3L_HIP(hipMemcpy2DAsync(pred_out[i], (size_t)pd[i] * 4, w.g[i].pred, (size_t)pdp[i] * 4, (size_t)pd[i] * 4, rows,
+                                     hipMemcpyDeviceToDevice, st));
+    }
+    return m3l_reduce_rows(w.loss_part, nparts, 1, 1, loss, 0, st);
+}
+
+int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                       const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream) {
+    if (check_geom(g)) return 1;
+    (void)tensors;
+    hipStream_t st = (hipStream_t)stream;
+    const Geo ge = geo_of(g);
+    HeadWs w = head_layout(ge, dd, dtype, B, nmask, ws);
+    const int cnt[2] = {nm_img, nmask - nm_img}, j0[2] = {0, nm_img};
+    const int pd[2] = {ge.pd_img, ge.pd_tac}, pdp[2] = {ge.pdp_img, ge.pdp_tac};
+    M3L_HIP(hipMemsetAsync(d_dec, 0, (size_t)B * N * dd * esz(dtype), st));
+    for (int i = 0; i < 2; ++i) {
+        if (cnt[i] == 0) continue;
+        const int rows = B * cnt[i];
+        const void* dpred = w.g[i].dpred;                 // d loss / d pred for dloss = 1 (written by the forward)
+        if (dloss) {
+            if (m3l_scale_by_dev(dtype, w.g[i].dpred, (long)rows * pdp[i], dloss, w.g[i].dpred_s, st)) return 1;
+            dpred = w.g[i].dpred_s;
+        }
+        if (m3l_gemm_tn(dtype, dpred, pdp[i], w.g[i].dg, dd, rows, pdp[i], dd, w.scratch, w.scratch_b, grads[2 * i], dd, pd[i], dd, 0, st))
+            return 1;
+        if (m3l_colsum(dtype, dpred, rows, pd[i], pdp[i], w.scratch, grads[2 * i + 1], 0, st)) return 1;
+        GemmEpi e = epi0(dd);
+        e.out_t = w.g[i].ddg;
+        if (m3l_gemm_nt(dtype, dpred, pdp[i], w.g[i].wT, pdp[i], rows, dd, pdp[i], &e, st)) return 1;
+        if (m3l_scatter_rows(dtype, w.g[i].ddg, N, dd, masked, nmask, j0[i], cnt[i], B, d_dec, st)) return 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stand-alone ops
+size_t m3l_layernorm_ws_bytes(int D) { return (size_t)M3L_MAX_PARTIAL_BLOCKS * 2 * D * sizeof(float) + 256; }
+
+int m3l_layernorm_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y,
+                      float* y32, void* stream) {
+    return m3l_ln_fwd(out_dtype, x, M, D, gamma, beta, eps, y, y32, (hipStream_t)stream);
+}
+int m3l_layernorm_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
+                      float* dx, void* ws, float* dgamma, float* dbeta, void* stream) {
+    return m3l_ln_bwd(dy_dtype, dy, x, M, D, gamma, eps, dres, dx, (float*)ws, dgamma, dbeta, 0, (hipStream_t)stream);
+}
+int m3l_gather_tokens(const float* src, int B, int N, int D, const int64_t* idx, int K, float* dst, void* stream) {
+    return m3l_gather_rows(0, src, N, D, idx, K, 0, K, B, dst, (hipStream_t)stream);
+}
+int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx, int K, float* dst_zeroed, void* stream) {
+    return m3l_scatter_rows(0, src, N, D, idx, K, 0, K, B, dst_zeroed, (hipStream_t)stream);
+}
+int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
+                int n_sensors, int frame_stack, float* const* tactile_out, void* stream) {
+    return m3l_vt_load_launch(image_nhwc, B, H, W, C, image_nchw, tactile, th, tw, n_sensors, frame_stack, tactile_out, (hipStream_t)stream);
+}
+
+int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                   const float* res, float* out_f32, void* out_t, void* out_pre, const void* gelu_u, int act, int ldc, void* stream) {
+    GemmEpi e = epi0(ldc);
+    e.bias = bias; e.res = res; e.out_f32 = out_f32; e.out_t = out_t; e.out_pre = out_pre; e.gelu_u = gelu_u; e.act = act;
+    return m3l_gemm_nt(dtype, A, lda, W, ldw, M, N, K, &e, (hipStream_t)stream);
+}
+size_t m3l_op_gemm_tn_ws_bytes(int M, int N, int K) { return m3l_gemm_tn_ws_bytes(M, N, K, nullptr); }
+int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, void* ws, size_t ws_bytes,
+                   float* out, int ldo, void* stream) {
+    return m3l_gemm_tn(dtype, Y, ldy, X, ldx, M, N, K, (float*)ws, ws_bytes, out, ldo, N, K, 0, (hipStream_t)stream);
+}
+int m3l_op_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, void* stream) {
+    return m3l_attn_fwd(dtype, qkv, o, lse, B, n, H, (hipStream_t)stream);
+}
+int m3l_op_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B,
+                    int n, int H, void* stream) {
+    return m3l_attn_bwd(dtype, qkv, o, dO, lse, dsum, dqkv, B, n, H, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+"""torch.autograd glue over the C ABI (include/m3l_amd.h).  PyTorch is plumbing here: it owns device memory, the
+current HIP stream and the autograd tape; every number is produced by the HIP kernels in m3l_amd/csrc.
+
+Each Function is one module of the reference's hot path (models/pretrain_models.py:146-342):
+  EmbedFn        patchify + LayerNorm/Linear/LayerNorm + modality + sincos (+ visible gather)   :157-216,255-256
+  TransformerFn  vit_pytorch.vit.Transformer.forward                                             :266,309
+  UnshuffleFn    enc_to_dec + mask tokens + decoder modality/sincos                              :270-307
+  HeadsLossFn    masked gather + to_pixels/to_tactiles + weighted MSE                            :260-262,327-340
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+DT_F32, DT_BF16 = 0, 1
+
+
+def dtype_code(compute_dtype) -> int:
+    if compute_dtype in ("bf16", torch.bfloat16, 1):
+        return DT_BF16
+    if compute_dtype in ("fp32", "f32", torch.float32, 0):
+        return DT_F32
+    raise ValueError(f"unsupported compute dtype {compute_dtype!r} (use 'fp32' or 'bf16')")
+
+
+def tdtype(code: int):
+    return torch.bfloat16 if code == DT_BF16 else torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise L.M3LError(f"{what} must live on the GPU: m3l_amd runs only on its HIP kernels (no CPU fallback)")
+
+
+def _f32c(t):
+    return t.detach().contiguous().float() if t is not None else None
+
+
+def _ws(nbytes: int, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def make_geom(enc, num_tactiles, use_vision=True, use_tactile=True) -> L.Geom:
+    return L.Geom(enc.image_height, enc.image_width, enc.image_patch_height, enc.image_channels,
+                  enc.tactile_height, enc.tactile_width, enc.tactile_patch_height, enc.tactile_channels,
+                  int(num_tactiles), int(bool(use_vision)), int(bool(use_tactile)))
+
+
+def mask_counts(geom: L.Geom, ratio: float):
+    out = (C.c_int * 6)()
+    L.check(L.lib().m3l_mask_counts(C.byref(geom), float(ratio), out), "m3l_mask_counts")
+    return dict(num_masked=out[0], num_unmasked=out[1], nm_img=out[2], nm_tac=out[3], n_img=out[4], n_tac=out[5])
+
+
+def mask_sample(geom: L.Geom, ratio: float, noises):
+    """noises: list of (B, n_i) f32 CUDA tensors in the reference's RNG order.  Returns int64 (masked, unmasked)."""
+    c = mask_counts(geom, ratio)
+    B = noises[0].shape[0]
+    dev = noises[0].device
+    noises = [_f32c(n) for n in noises]
+    for n in noises:
+        _require_cuda(n, "mask noise")
+    masked = torch.empty(B, c["num_masked"], dtype=torch.int64, device=dev)
+    unmasked = torch.empty(B, c["num_unmasked"], dtype=torch.int64, device=dev)
+    L.check(L.lib().m3l_mask_sample(C.byref(geom), float(ratio), B, L.ptr_array(noises), L.ptr(masked), L.ptr(unmasked),
+                                    _stream()), "m3l_mask_sample")
+    return masked, unmasked, c
+
+
+# -------------------------------------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    """inputs: image / tactile tensors (no grad), then the 15 tensors of the embed group (see header)."""
+
+    @staticmethod
+    def forward(ctx, geom, D, dt, idx, cnt_img, L_tok, image, tactiles, *tensors):
+        ref = image if image is not None else tactiles[0]
+        _require_cuda(ref, "MAE input")
+        B, dev = ref.shape[0], ref.device
+        image = _f32c(image)
+        tactiles = [_f32c(t) for t in tactiles]
+        tens = [_f32c(t) for t in tensors]
+        ws = _ws(L.lib().m3l_embed_ws_bytes(C.byref(geom), D, dt, B, L_tok), dev)
+        tokens = torch.empty(B, L_tok, D, dtype=torch.float32, device=dev)
+        tac_arr = L.ptr_array(tactiles)
+        L.check(L.lib().m3l_embed_fwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image), tac_arr,
+                                      L.ptr_array(tens), L.ptr(ws), L.ptr(tokens), _stream()), "m3l_embed_fwd")
+        ctx.saved = (geom, D, dt, idx, cnt_img, L_tok, image, tactiles, tens, ws)
+        ctx.n_t = len(tensors)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtokens):
+        geom, D, dt, idx, cnt_img, L_tok, image, tactiles, tens, ws = ctx.saved
+        B = dtokens.shape[0]
+        dtokens = _f32c(dtokens)
+        # parameters of a modality that is absent from this call stay without gradient (as in the reference graph)
+        used = [image is not None] * 6 + [len(tactiles) > 0] * 6 + [True]
+        grads = [torch.zeros_like(t) if (t is not None and i < 13 and used[i]) else None for i, t in enumerate(tens)]
+        L.check(L.lib().m3l_embed_bwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image),
+                                      L.ptr_array(tactiles), L.ptr_array(tens), L.ptr(ws), L.ptr(dtokens),
+                                      L.ptr_array(grads), _stream()), "m3l_embed_bwd")
+        return (None,) * 8 + tuple(grads)
+
+
+class TransformerFn(torch.autograd.Function):
+    """x (B, n, D) f32 -> (y_t compute-type, y32 f32) = final LayerNorm output, twice (the heads consume the
+    compute-type copy, torch-side consumers the f32 one)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *tensors):
+        _require_cuda(x, "transformer input")
+        B, n, D = x.shape
+        assert D == cfg.dim, (D, cfg.dim)
+        x = _f32c(x)
+        tens = [_f32c(t) for t in tensors]
+        ws = _ws(L.lib().m3l_transformer_ws_bytes(C.byref(cfg), B, n), x.device)
+        y32 = torch.empty(B, n, D, dtype=torch.float32, device=x.device)
+        y_t = torch.empty(B, n, D, dtype=torch.bfloat16, device=x.device) if cfg.dtype == DT_BF16 else None
+        L.check(L.lib().m3l_transformer_fwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws),
+                                            L.ptr(y_t), L.ptr(y32), _stream()), "m3l_transformer_fwd")
+        ctx.saved = (cfg, x, tens, ws)
+        if y_t is None:
+            y_t = y32.clone()     # f32 compute: two distinct autograd outputs over the same values
+        return y_t, y32
+
+    @staticmethod
+    def backward(ctx, dy_t, dy32):
+        cfg, x, tens, ws = ctx.saved
+        B, n, D = x.shape
+        if dy_t is not None and dy32 is not None:
+            dy, code = (dy32 + dy_t.float()).contiguous(), DT_F32
+        elif dy_t is not None:
+            dy = dy_t.contiguous()
+            code = DT_BF16 if dy.dtype == torch.bfloat16 else DT_F32
+        else:
+            dy, code = _f32c(dy32), DT_F32
+        grads = [torch.zeros_like(t) if t is not None else None for t in tens]
+        dx = torch.empty_like(x)
+        L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
+                                            L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
+        return (None, dx) + tuple(grads)
+
+
+class UnshuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, D, dd, dt, unmasked, masked, enc_t, enc32, *tensors):
+        B, nvis = unmasked.shape
+        nmask = masked.shape[1]
+        dev = enc32.device
+        tens = [_f32c(t) for t in tensors]
+        ws = _ws(L.lib().m3l_unshuffle_ws_bytes(C.byref(geom), D, dd, dt, B, nvis, nmask), dev)
+        dec_in = torch.empty(B, nvis + nmask, dd, dtype=torch.float32, device=dev)
+        enc_t = enc_t.contiguous()
+        enc32 = enc32.contiguous()
+        L.check(L.lib().m3l_unshuffle_fwd(C.byref(geom), D, dd, dt, B, nvis, nmask, L.ptr(unmasked), L.ptr(masked),
+                                          L.ptr(enc32), L.ptr(enc_t), L.ptr_array(tens), L.ptr(ws), L.ptr(dec_in),
+                                          _stream()), "m3l_unshuffle_fwd")
+        ctx.saved = (geom, D, dd, dt, unmasked, masked, enc_t, tens, ws)
+        return dec_in
+
+    @staticmethod
+    def backward(ctx, d_dec_in):
+        geom, D, dd, dt, unmasked, masked, enc_t, tens, ws = ctx.saved
+        B, nvis = unmasked.shape
+        nmask = masked.shape[1]
+        dev = d_dec_in.device
+        d_dec_in = _f32c(d_dec_in)
+        proj = tens[0] is not None
+        d_enc = torch.empty(B, nvis, D, dtype=(tdtype(dt) if proj else torch.float32), device=dev)
+        grads = [torch.zeros_like(t) if (t is not None and i < 4) else None for i, t in enumerate(tens)]
+        code = C.c_int(0)
+        L.check(L.lib().m3l_unshuffle_bwd(C.byref(geom), D, dd, dt, B, nvis, nmask, L.ptr(unmasked), L.ptr(masked),
+                                          L.ptr(enc_t), L.ptr_array(tens), L.ptr(ws), L.ptr(d_dec_in), L.ptr(d_enc),
+                                          C.byref(code), L.ptr_array(grads), _stream()), "m3l_unshuffle_bwd")
+        if proj:      # gradient flows through the compute-type encoder output
+            return (None,) * 6 + (d_enc, None) + tuple(grads)
+        return (None,) * 6 + (None, d_enc) + tuple(grads)
+
+
+class HeadsLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, dd, dt, masked, nm_img, image, tactiles, dump, dec_t, *tensors):
+        B, N, _ = dec_t.shape
+        nmask = masked.shape[1]
+        dev = dec_t.device
+        image = _f32c(image)
+        tactiles = [_f32c(t) for t in tactiles]
+        tens = [_f32c(t) for t in tensors]
+        dec_t = dec_t.contiguous()
+        ws = _ws(L.lib().m3l_heads_ws_bytes(C.byref(geom), dd, dt, B, nmask), dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        outs = [None] * 4
+        if dump is not None:
+            pd_i = geom.image_channels * geom.image_patch ** 2
+            pd_t = geom.tactile_channels * geom.tactile_patch ** 2
+            n_t = nmask - nm_img
+            outs = [torch.zeros(B, nm_img, pd_i, device=dev), torch.zeros(B, nm_img, pd_i, device=dev),
+                    torch.zeros(B, n_t, pd_t, device=dev), torch.zeros(B, n_t, pd_t, device=dev)]
+            dump.update(pred_pixel=outs[0], target_pixel=outs[1], pred_tactile=outs[2], target_tactile=outs[3])
+        L.check(L.lib().m3l_heads_loss_fwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr(image),
+                                           L.ptr_array(tactiles), L.ptr(dec_t), L.ptr_array(tens), L.ptr(ws), L.ptr(loss),
+                                           L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), _stream()),
+                "m3l_heads_loss_fwd")
+        ctx.saved = (geom, dd, dt, masked, nm_img, tens, ws, (B, N), dec_t.dtype)
+        ctx.used = [image is not None] * 2 + [len(tactiles) > 0] * 2
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        geom, dd, dt, masked, nm_img, tens, ws, (B, N), ddtype = ctx.saved
+        nmask = masked.shape[1]
+        dloss = _f32c(dloss)
+        d_dec = torch.empty(B, N, dd, dtype=ddtype, device=dloss.device)
+        grads = [torch.zeros_like(t) if (t is not None and ctx.used[i]) else None for i, t in enumerate(tens)]
+        L.check(L.lib().m3l_heads_loss_bwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr_array(tens),
+                                           L.ptr(ws), L.ptr(dloss), L.ptr(d_dec), L.ptr_array(grads), _stream()),
+                "m3l_heads_loss_bwd")
+        return (None,) * 8 + (d_dec,) + tuple(grads)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of an f32 tensor (final norm of the DINO-style encoder, models/VTT.py:354)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_cuda(x, "layernorm input")
+        x = _f32c(x)
+        D = x.shape[-1]
+        M = x.numel() // D
+        y = torch.empty_like(x)
+        L.check(L.lib().m3l_layernorm_fwd(DT_F32, L.ptr(x), M, D, L.ptr(_f32c(gamma)), L.ptr(_f32c(beta)), float(eps),
+                                          L.ptr(y), None, _stream()), "m3l_layernorm_fwd")
+        ctx.saved = (x, _f32c(gamma), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, eps = ctx.saved
+        D = x.shape[-1]
+        M = x.numel() // D
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        ws = _ws(L.lib().m3l_layernorm_ws_bytes(D), x.device)
+        L.check(L.lib().m3l_layernorm_bwd(DT_F32, L.ptr(dy), L.ptr(x), M, D, L.ptr(gamma), eps, None, L.ptr(dx), L.ptr(ws),
+                                          L.ptr(dg), L.ptr(db), _stream()), "m3l_layernorm_bwd")
+        return dx, dg, db, None
+
+
+class GatherTokensFn(torch.autograd.Function):
+    """x (B, N, D) f32, idx (B, K) int64 -> (B, K, D)   [tactile_ssl.utils.apply_masks for one mask]."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        _require_cuda(x, "gather input")
+        x = _f32c(x)
+        idx = idx.contiguous()
+        B, N, D = x.shape
+        K = idx.shape[1]
+        y = torch.empty(B, K, D, dtype=torch.float32, device=x.device)
+        L.check(L.lib().m3l_gather_tokens(L.ptr(x), B, N, D, L.ptr(idx), K, L.ptr(y), _stream()), "m3l_gather_tokens")
+        ctx.saved = (idx, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, N = ctx.saved
+        dy = _f32c(dy)
+        B, K, D = dy.shape
+        dx = torch.zeros(B, N, D, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().m3l_scatter_tokens(L.ptr(dy), B, N, D, L.ptr(idx), K, L.ptr(dx), _stream()), "m3l_scatter_tokens")
+        return dx, None

@@ -1,0 +1,285 @@
+"""Drop-in `VTT` / `VTMAE` (+ the `Transformer` they hold) with the reference's constructor kwargs, attribute names,
+parameter names/shapes and forward signatures — reference: /root/reference/models/pretrain_models.py:59-786 and
+vit-pytorch 1.6.4 `vit_pytorch.vit.Transformer` (third party).  Same construction ORDER as the reference, so
+`torch.manual_seed(s)` followed by construction yields the reference's initial weights.
+
+The nn.Modules here are parameter containers + orchestration; all arithmetic of the hot path runs in the HIP kernels of
+m3l_amd/csrc through the C ABI (include/m3l_amd.h).  There is no eager/CPU fallback: inputs must be CUDA (ROCm) tensors.
+
+Extensions over the reference signature (all optional, defaults keep reference behaviour):
+  * `VTMAE.forward(..., mask_noise=[...])`: inject the uniform noise the reference would draw with torch.rand
+    (one (B, n) tensor per modality in RNG order image, tactile1..k).  Needed for bit-exact mask parity.
+  * `compute_dtype='fp32' | 'bf16'` (constructor kwarg / `set_compute_dtype`): bf16 = bf16 MFMA operands, fp32
+    accumulation, fp32 master weights, fp32 residual stream.
+"""
+import math
+
+import torch
+import torch.optim as optim
+from torch import nn
+
+from . import _lib as L
+from . import functional as Fn
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class Rearrange(nn.Module):
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (einops Rearrange of the reference, pretrain_models.py:768,775).
+    Kept so that `encoder.image_to_patch_embedding[0]` exists and is callable; the MAE path itself patchifies
+    inside the fused HIP gather kernel."""
+
+    def __init__(self, p1, p2):
+        super().__init__()
+        self.p1, self.p2 = p1, p2
+
+    def forward(self, x):
+        b, c, H, W = x.shape
+        h, w = H // self.p1, W // self.p2
+        return x.reshape(b, c, h, self.p1, w, self.p2).permute(0, 2, 4, 3, 5, 1).reshape(b, h * w, self.p1 * self.p2 * c)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("m3l_amd attention kernels are built for dim_head = 64 (all reference configs)")
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.norm = nn.LayerNorm(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class Transformer(nn.Module):
+    """Parameter layout of vit_pytorch.vit.Transformer; forward runs the HIP transformer stack."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        if dropout != 0.:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path (the reference trains with dropout = 0)")
+        self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
+        self.project_out = not (heads == 1 and dim_head == dim)
+        self.compute_dtype = "fp32"
+        self.norm = nn.LayerNorm(dim)
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout),
+                                              FeedForward(dim, mlp_dim, dropout=dropout)]))
+
+    def _tensors(self):
+        t = []
+        for attn, ff in self.layers:
+            out = attn.to_out[0] if self.project_out else None
+            t += [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight,
+                  out.weight if out is not None else None, out.bias if out is not None else None,
+                  ff.net[0].weight, ff.net[0].bias, ff.net[1].weight, ff.net[1].bias, ff.net[4].weight, ff.net[4].bias]
+        return t + [self.norm.weight, self.norm.bias]
+
+    def _cfg(self):
+        return L.TfCfg(self.dim, self.depth, self.heads, self.mlp_dim, int(self.project_out), Fn.dtype_code(self.compute_dtype))
+
+    def run(self, x):
+        """-> (y in compute dtype, y in f32); both carry gradient."""
+        return Fn.TransformerFn.apply(self._cfg(), x, *self._tensors())
+
+    def forward(self, x):
+        return self.run(x)[1]
+
+
+class VTT(nn.Module):
+    """Encoder container of the reference (pretrain_models.py:717-786): two patch-embed Sequentials, learned
+    pos_embedding (unused under sincos), Transformer.  Like the reference it has no forward."""
+
+    def __init__(self, *, image_size, tactile_size, image_patch_size, tactile_patch_size, dim, depth, heads, mlp_dim,
+                 image_channels=3, tactile_channels=3, dim_head=64, dropout=0., emb_dropout=0, num_tactiles=2, frame_stack=1):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        tactile_height, tactile_width = pair(tactile_size)
+        image_patch_height, image_patch_width = pair(image_patch_size)
+        tactile_patch_height, tactile_patch_width = pair(tactile_patch_size)
+        self.image_height, self.image_width = image_height, image_width
+        self.tactile_height, self.tactile_width = tactile_height, tactile_width
+        self.image_patch_height, self.image_patch_width = image_patch_height, image_patch_width
+        self.tactile_patch_height, self.tactile_patch_width = tactile_patch_height, tactile_patch_width
+        self.image_channels, self.tactile_channels = image_channels, tactile_channels
+        self.frame_stack = frame_stack
+        assert image_height % image_patch_height == 0 and image_width % image_patch_width == 0, 'Image dimensions must be divisible by the patch size.'
+        assert tactile_height % tactile_patch_height == 0 and tactile_width % tactile_patch_width == 0, 'Tactile dimensions must be divisible by the patch size.'
+        if image_patch_height != image_patch_width or tactile_patch_height != tactile_patch_width:
+            raise NotImplementedError("m3l_amd supports square patches (all reference configs)")
+        num_patches_image = (image_height // image_patch_height) * (image_width // image_patch_width)
+        num_patches_tactile = (tactile_height // tactile_patch_height) * (tactile_width // tactile_patch_width) * num_tactiles
+        num_patches = num_patches_image + num_patches_tactile
+        image_patch_dim = image_channels * image_patch_height * image_patch_width
+        tactile_patch_dim = tactile_channels * tactile_patch_height * tactile_patch_width
+        self.image_to_patch_embedding = nn.Sequential(
+            Rearrange(image_patch_height, image_patch_width), nn.LayerNorm(image_patch_dim),
+            nn.Linear(image_patch_dim, dim), nn.LayerNorm(dim))
+        self.tactile_to_patch_embedding = nn.Sequential(
+            Rearrange(tactile_patch_height, tactile_patch_width), nn.LayerNorm(tactile_patch_dim),
+            nn.Linear(tactile_patch_dim, dim), nn.LayerNorm(dim))
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.to_latent = nn.Identity()
+
+
+def _sincos_2d(channels_param, gh, gw, out_ch):
+    """positional-encodings 6.0.1 `PositionalEncoding2D(channels_param)` on a (1, gh, gw, out_ch) tensor -> (1, gh*gw, out_ch)
+    (reference call sites pretrain_models.py:120-140: ONE object parameterised by the encoder dim is reused for the
+    decoder buffers, which therefore hold the first decoder_dim channels of the encoder-dim code)."""
+    ch = int(math.ceil(channels_param / 4) * 2)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+
+    def emb(n):
+        s = torch.einsum("i,j->ij", torch.arange(n).float(), inv_freq)
+        return torch.stack((s.sin(), s.cos()), dim=-1).flatten(-2, -1)
+    e = torch.zeros(gh, gw, 2 * ch)
+    e[:, :, :ch] = emb(gh).unsqueeze(1)
+    e[:, :, ch:2 * ch] = emb(gw)
+    return e[None, :, :, :out_ch].reshape(1, gh * gw, -1)
+
+
+class VTMAE(nn.Module):
+    def __init__(self, *, encoder, decoder_dim, masking_ratio=0.75, decoder_depth=1, decoder_heads=8, decoder_dim_head=64,
+                 num_tactiles=2, early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=1, compute_dtype="fp32"):
+        super().__init__()
+        assert masking_ratio > 0 and masking_ratio < 1, 'masking ratio must be kept between 0 and 1'
+        if early_conv_masking:
+            raise NotImplementedError("early_conv_masking=True (EarlyCNN stem, pretrain_models.py:37-56) is not built yet (SURVEY 8f-2)")
+        if not use_sincosmod_encodings:
+            raise NotImplementedError("use_sincosmod_encodings=False (learned positions) is not built in the HIP path")
+        self.masking_ratio = masking_ratio
+        self.num_tactiles = num_tactiles
+        self.frame_stack = frame_stack
+        self.encoder = encoder
+        num_patches, encoder_dim = encoder.pos_embedding.shape[-2:]
+        num_decoder_patches = num_patches - 1
+        self.use_sincosmod_encodings = use_sincosmod_encodings
+        self.early_conv_masking = early_conv_masking
+
+        self.image_to_patch = encoder.image_to_patch_embedding[0]
+        self.image_patch_to_emb = nn.Sequential(*encoder.image_to_patch_embedding[1:])
+        pixel_values_per_patch = encoder.image_to_patch_embedding[2].weight.shape[-1]
+        self.tactile_to_patch = encoder.tactile_to_patch_embedding[0]
+        self.tactile_patch_to_emb = nn.Sequential(*encoder.tactile_to_patch_embedding[1:])
+        tactile_values_per_patch = encoder.tactile_to_patch_embedding[2].weight.shape[-1]
+        self.encoder_dim = encoder_dim
+
+        self.decoder_dim = decoder_dim
+        self.enc_to_dec = nn.Linear(encoder_dim, decoder_dim) if encoder_dim != decoder_dim else nn.Identity()
+        self.mask_token = nn.Parameter(torch.randn(decoder_dim))
+        self.decoder = Transformer(dim=decoder_dim, depth=decoder_depth, heads=decoder_heads, dim_head=decoder_dim_head,
+                                   mlp_dim=decoder_dim * 4)
+        self.decoder_pos_emb = nn.Embedding(num_decoder_patches, decoder_dim)
+        self.to_pixels = nn.Linear(decoder_dim, pixel_values_per_patch)
+        self.to_tactiles = nn.Linear(decoder_dim, tactile_values_per_patch)
+
+        gh, gw = encoder.image_height // encoder.image_patch_height, encoder.image_width // encoder.image_patch_width
+        th, tw = encoder.tactile_height // encoder.tactile_patch_height, encoder.tactile_width // encoder.tactile_patch_width
+        if decoder_dim > 2 * int(math.ceil(encoder_dim / 4) * 2):
+            raise ValueError("decoder_dim larger than the encoder-dim sincos code (the reference fails with a shape error here)")
+        self.register_buffer('image_enc_pos_embedding', _sincos_2d(encoder_dim, gh, gw, encoder_dim))
+        self.register_buffer('tactile_enc_pos_embedding', _sincos_2d(encoder_dim, th, tw, encoder_dim).repeat(1, num_tactiles, 1))
+        self.register_buffer('image_dec_pos_embedding', _sincos_2d(encoder_dim, gh, gw, decoder_dim))
+        self.register_buffer('tactile_dec_pos_embedding', _sincos_2d(encoder_dim, th, tw, decoder_dim).repeat(1, num_tactiles, 1))
+
+        self.encoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), encoder_dim)
+        self.decoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), decoder_dim)
+        self.set_compute_dtype(compute_dtype)
+        self.last_mask = None       # (masked_indices, unmasked_indices) of the latest forward, int64 (B, *)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def set_compute_dtype(self, compute_dtype):
+        Fn.dtype_code(compute_dtype)
+        self.compute_dtype = compute_dtype
+        self.encoder.transformer.compute_dtype = compute_dtype
+        self.decoder.compute_dtype = compute_dtype
+        return self
+
+    def _embed_tensors(self):
+        i, t = self.encoder.image_to_patch_embedding, self.encoder.tactile_to_patch_embedding
+        return [i[1].weight, i[1].bias, i[2].weight, i[2].bias, i[3].weight, i[3].bias,
+                t[1].weight, t[1].bias, t[2].weight, t[2].bias, t[3].weight, t[3].bias,
+                self.encoder_modality_embedding.weight, self.image_enc_pos_embedding[0], self.tactile_enc_pos_embedding[0]]
+
+    def _glue_tensors(self):
+        e2d = isinstance(self.enc_to_dec, nn.Linear)
+        return [self.enc_to_dec.weight if e2d else None, self.enc_to_dec.bias if e2d else None, self.mask_token,
+                self.decoder_modality_embedding.weight, self.image_dec_pos_embedding[0], self.tactile_dec_pos_embedding[0]]
+
+    def _head_tensors(self):
+        return [self.to_pixels.weight, self.to_pixels.bias, self.to_tactiles.weight, self.to_tactiles.bias]
+
+    def _inputs(self, x, use_vision, use_tactile):
+        if 'image' not in x.keys():
+            use_vision = False
+        use_tactile = bool(use_tactile) and self.num_tactiles > 0
+        image = x['image'] if use_vision else None
+        tactiles = [x['tactile' + str(i)] for i in range(1, self.num_tactiles + 1)] if use_tactile else []
+        ref = image if image is not None else (tactiles[0] if tactiles else None)
+        if ref is None:
+            raise ValueError("neither image nor tactile inputs in use")
+        geom = Fn.make_geom(self.encoder, self.num_tactiles, use_vision, use_tactile)
+        return image, tactiles, geom, ref
+
+    def _tokens(self, geom, image, tactiles, idx, cnt_img, L_tok):
+        dt = Fn.dtype_code(self.compute_dtype)
+        return Fn.EmbedFn.apply(geom, self.encoder_dim, dt, idx, cnt_img, L_tok, image, tactiles, *self._embed_tensors())
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, x, use_vision=True, use_tactile=True, mask_noise=None, dump=None):
+        """Reconstruction loss (0-dim tensor with grad), pretrain_models.py:146-342."""
+        image, tactiles, geom, ref = self._inputs(x, use_vision, use_tactile)
+        B, dev = ref.shape[0], ref.device
+        dt = Fn.dtype_code(self.compute_dtype)
+        c = Fn.mask_counts(geom, self.masking_ratio)
+        sizes = ([c["n_img"]] if image is not None else []) + [c["n_tac"]] * len(tactiles)
+        if mask_noise is None:
+            mask_noise = [torch.rand(B, n, device=dev) for n in sizes]          # reference RNG order (:229,:237)
+        assert [tuple(n.shape) for n in mask_noise] == [(B, n) for n in sizes], "mask_noise: one (B, n) tensor per modality"
+        masked, unmasked, _ = Fn.mask_sample(geom, self.masking_ratio, [n.to(dev) for n in mask_noise])
+        self.last_mask = (masked, unmasked)
+        nvis_img = c["n_img"] - c["nm_img"]
+
+        tokens = self._tokens(geom, image, tactiles, unmasked, nvis_img, c["num_unmasked"])
+        enc_t, enc32 = self.encoder.transformer.run(tokens)
+        dec_in = Fn.UnshuffleFn.apply(geom, self.encoder_dim, self.decoder_dim, dt, unmasked, masked, enc_t, enc32,
+                                      *self._glue_tensors())
+        dec_t, _ = self.decoder.run(dec_in)
+        loss = Fn.HeadsLossFn.apply(geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles, dump, dec_t,
+                                    *self._head_tensors())
+        if dump is not None:
+            dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens, encoder_out=enc32,
+                        decoder_in=dec_in, decoder_out=dec_t)
+        return loss
+
+    def get_embeddings(self, x, eval=True, use_vision=True, use_tactile=True):
+        """Encoder over ALL tokens, no masking (pretrain_models.py:588-668) -> (B, N, D) f32 with grad."""
+        if eval:
+            self.eval()
+        else:
+            self.train()
+        image, tactiles, geom, _ = self._inputs(x, use_vision, use_tactile)
+        c = Fn.mask_counts(geom, self.masking_ratio)
+        N = c["num_masked"] + c["num_unmasked"]
+        tokens = self._tokens(geom, image, tactiles, None, c["n_img"], N)
+        return self.encoder.transformer(tokens)
+
+    def initialize_training(self, train_args):
+        self.optimizer = optim.AdamW(self.parameters(), lr=train_args['lr'])
+        self.batch_size = train_args['batch_size']

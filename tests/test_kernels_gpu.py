@@ -1,0 +1,179 @@
+"""Per-kernel numerics on a real MI355X: every hand-written HIP kernel, through the C ABI, against a plain PyTorch fp32
+reference of the same op (fp32 compute: tight tolerance; bf16 compute: bf16-rounding tolerance)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from m3l_amd import _lib as L  # noqa: E402
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _t(code):
+    return torch.bfloat16 if code else torch.float32
+
+
+def _tol(code):
+    return dict(rtol=2e-2, atol=2e-2) if code else dict(rtol=2e-4, atol=2e-4)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    L.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 192, 192), (77, 48, 48), (1000, 576, 192), (129, 200, 776), (64, 8, 8)])
+def test_gemm_nt_plain(dev, code, M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev).to(_t(code))
+    W = torch.randn(N, K, device=dev).to(_t(code))
+    bias = torch.randn(N, device=dev)
+    out32 = torch.full((M, N), float("nan"), device=dev)
+    out_t = torch.zeros(M, N, device=dev, dtype=_t(code))
+    L.check(L.lib().m3l_op_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, M, N, K, L.ptr(bias), None, L.ptr(out32), L.ptr(out_t),
+                                   None, None, 0, N, _s()), "gemm_nt")
+    ref = A.float() @ W.float().t() + bias
+    scale = ref.abs().max().item()
+    assert (out32 - ref).abs().max().item() <= (3e-3 if code else 2e-5) * scale + 1e-5
+    torch.testing.assert_close(out_t.float(), ref, rtol=2e-2 if code else 1e-4, atol=(2e-2 if code else 1e-4) * scale)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_gemm_nt_asymmetric_layout(dev, code):
+    """A = I against an ASYMMETRIC W catches a swapped row/col accumulator map (guide: 'Always A=I-check with asymmetric B')."""
+    M = N = K = 128
+    A = torch.eye(M, device=dev).to(_t(code))
+    W = (torch.arange(N, device=dev)[:, None] * 2 + torch.arange(K, device=dev)[None, :] % 7).float().to(_t(code))
+    out32 = torch.zeros(M, N, device=dev)
+    L.check(L.lib().m3l_op_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, M, N, K, None, None, L.ptr(out32), None, None, None, 0, N, _s()), "gemm_nt")
+    torch.testing.assert_close(out32, W.float().t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_gemm_nt_epilogues(dev, code):
+    torch.manual_seed(5)
+    M, N, K = 200, 256, 64
+    A = (0.3 * torch.randn(M, K, device=dev)).to(_t(code))
+    W = (0.3 * torch.randn(N, K, device=dev)).to(_t(code))
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    # GELU + pre-activation copy (fc1)
+    u = torch.zeros(M, N, device=dev, dtype=_t(code))
+    h = torch.zeros(M, N, device=dev, dtype=_t(code))
+    L.check(L.lib().m3l_op_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, M, N, K, L.ptr(bias), None, None, L.ptr(h), L.ptr(u), None, 1, N, _s()), "fc1")
+    ref_u = A.float() @ W.float().t() + bias
+    torch.testing.assert_close(u.float(), ref_u, **_tol(code))
+    torch.testing.assert_close(h.float(), torch.nn.functional.gelu(u.float()), **_tol(code))
+    # bias + residual into f32 (out-proj / fc2)
+    out = torch.zeros(M, N, device=dev)
+    L.check(L.lib().m3l_op_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, M, N, K, L.ptr(bias), L.ptr(res), L.ptr(out), None, None, None, 0, N, _s()), "res")
+    torch.testing.assert_close(out, ref_u + res, **_tol(code))
+    # dgrad through GELU: acc * gelu'(u)
+    du = torch.zeros(M, N, device=dev, dtype=_t(code))
+    L.check(L.lib().m3l_op_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, M, N, K, None, None, None, L.ptr(du), None, L.ptr(u), 0, N, _s()), "dgelu")
+    uu = u.float().clone().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    torch.testing.assert_close(du.float(), (A.float() @ W.float().t()) * uu.grad, **_tol(code))
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(512, 128, 128), (1000, 192, 576), (333, 48, 192), (4096, 768, 192), (70, 8, 200)])
+def test_gemm_tn(dev, code, M, N, K):
+    torch.manual_seed(M + N)
+    Y = torch.randn(M, N, device=dev).to(_t(code))
+    X = torch.randn(M, K, device=dev).to(_t(code))
+    nb = L.lib().m3l_op_gemm_tn_ws_bytes(M, N, K)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out = torch.full((N, K), float("nan"), device=dev)
+    L.check(L.lib().m3l_op_gemm_tn(code, L.ptr(Y), N, L.ptr(X), K, M, N, K, L.ptr(ws), nb, L.ptr(out), K, _s()), "gemm_tn")
+    ref = Y.float().t() @ X.float()
+    assert (out - ref).abs().max().item() <= (2e-3 if code else 2e-5) * ref.abs().max().item() + 1e-4
+
+
+def _attn_ref(qkv, B, n, H):
+    q, k, v = [t.reshape(B, n, H, 64).transpose(1, 2) for t in qkv.float().reshape(B, n, 3 * H * 64).chunk(3, dim=-1)]
+    dots = (q @ k.transpose(-1, -2)) * 0.125
+    o = (dots.softmax(-1) @ v).transpose(1, 2).reshape(B * n, H * 64)
+    return o, torch.logsumexp(dots, -1)     # (B*n, H*64), (B, H, n)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("B,n,H", [(2, 48, 3), (3, 16, 1), (2, 10, 4), (2, 75, 2), (1, 192, 3), (1, 113, 6), (1, 452, 1)])
+def test_attention_fwd_bwd(dev, code, B, n, H):
+    torch.manual_seed(n * 7 + H)
+    qkv = torch.randn(B * n, 3 * H * 64, device=dev).to(_t(code))
+    dO = torch.randn(B * n, H * 64, device=dev).to(_t(code))
+    o = torch.zeros(B * n, H * 64, device=dev, dtype=_t(code))
+    lse = torch.zeros(B, H, n, device=dev)
+    L.check(L.lib().m3l_op_attn_fwd(code, L.ptr(qkv), L.ptr(o), L.ptr(lse), B, n, H, _s()), "attn_fwd")
+    ref_in = qkv.float().clone().requires_grad_(True)
+    ref_o, ref_lse = _attn_ref(ref_in, B, n, H)
+    torch.testing.assert_close(o.float(), ref_o, **_tol(code))
+    torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=2e-2 if code else 1e-4)
+    dsum = torch.zeros(B, H, n, device=dev)
+    dqkv = torch.full_like(qkv, float("nan"))
+    L.check(L.lib().m3l_op_attn_bwd(code, L.ptr(qkv), L.ptr(o), L.ptr(dO), L.ptr(lse), L.ptr(dsum), L.ptr(dqkv), B, n, H, _s()), "attn_bwd")
+    (ref_o * dO.float()).sum().backward()
+    scale = ref_in.grad.abs().max().item()
+    assert (dqkv.float() - ref_in.grad).abs().max().item() <= (4e-2 if code else 2e-4) * scale + 1e-5
+
+
+def test_attention_softmax_spike(dev):
+    """One key dominating from a late tile forces the online-softmax rescale branch (guide rule 26)."""
+    B, n, H = 1, 96, 1
+    torch.manual_seed(3)
+    qkv = 0.1 * torch.randn(B * n, 192, device=dev)
+    qkv[5, 0:64] = 4.0        # query 5
+    qkv[80, 64:128] = 4.0     # key 80 (third 32-key tile) lines up with it -> score 4*4*64/8 = 128 >> others
+    o = torch.zeros(B * n, 64, device=dev)
+    lse = torch.zeros(B, H, n, device=dev)
+    L.check(L.lib().m3l_op_attn_fwd(0, L.ptr(qkv), L.ptr(o), L.ptr(lse), B, n, H, _s()), "attn_fwd")
+    ref_o, ref_lse = _attn_ref(qkv, B, n, H)
+    torch.testing.assert_close(o, ref_o, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(lse, ref_lse, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("D", [48, 64, 192, 384, 592, 768])
+def test_layernorm_fwd_bwd(dev, D):
+    torch.manual_seed(D)
+    M = 1031
+    x = torch.randn(M, D, device=dev) * 2 + 0.5
+    g = torch.randn(D, device=dev)
+    b = torch.randn(D, device=dev)
+    y = torch.zeros(M, D, device=dev)
+    L.check(L.lib().m3l_layernorm_fwd(0, L.ptr(x), M, D, L.ptr(g), L.ptr(b), 1e-5, L.ptr(y), None, _s()), "ln_fwd")
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    dy = torch.randn(M, D, device=dev)
+    res = torch.randn(M, D, device=dev)
+    dx = torch.zeros(M, D, device=dev)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ws = torch.empty(L.lib().m3l_layernorm_ws_bytes(D), dtype=torch.uint8, device=dev)
+    L.check(L.lib().m3l_layernorm_bwd(0, L.ptr(dy), L.ptr(x), M, D, L.ptr(g), 1e-5, L.ptr(res), L.ptr(dx), L.ptr(ws), L.ptr(dg), L.ptr(db), _s()), "ln_bwd")
+    ref.backward(dy)
+    torch.testing.assert_close(dx, xr.grad + res, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db, br.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_vt_load_matches_golden(dev, golden_dir):
+    import os
+    import numpy as np
+    from m3l_amd import vt_load
+    for fs in (1, 2):
+        z = np.load(os.path.join(golden_dir, f"vt_load_fs{fs}.npz"))
+        out = vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, frame_stack=fs)
+        assert sorted(out.keys()) == sorted(k[4:] for k in z.files if k.startswith("out/"))
+        for k, v in out.items():
+            assert v.dtype == torch.float32 and v.is_cuda
+            np.testing.assert_array_equal(v.cpu().numpy(), z["out/" + k])

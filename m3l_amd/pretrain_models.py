@@ -264,8 +264,8 @@ class VTMAE(nn.Module):
         loss = Fn.HeadsLossFn.apply(geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles, dump, dec_t,
                                     *self._head_tensors())
         if dump is not None:
-            dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens, encoder_out=enc32,
-                        decoder_in=dec_in, decoder_out=dec_t)
+            dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens.detach(), encoder_out=enc32.detach(),
+                        decoder_in=dec_in.detach(), decoder_out=dec_t.detach())
         return loss
 
     def get_embeddings(self, x, eval=True, use_vision=True, use_tactile=True):

@@ -63,7 +63,7 @@ def test_golden_fp32(golden_dir, name):
     assert masked.dtype == np.int64
     ref_perm_rows_equal(z, masked, unmasked, cfg)
     # loss: 1e-4 relative (north star, fp32)
-    assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"])), (float(loss), float(z["loss"]))
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"])), (float(loss.detach()), float(z["loss"]))
     # intermediates that do not depend on the (unspecified) order of tied keys inside the masked list
     np.testing.assert_allclose(dump["encoder_in"].cpu().numpy(), z["cap/encoder_in"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(dump["encoder_out"].cpu().numpy(), z["cap/encoder_out"], rtol=1e-3, atol=1e-4)
@@ -91,7 +91,7 @@ def test_golden_bf16_loss(golden_dir, name):
     x, noises = inputs_of(z)
     loss = mae(x, mask_noise=noises)
     loss.backward()
-    assert abs(float(loss) - float(z["loss"])) <= 1e-2 * abs(float(z["loss"])), (float(loss), float(z["loss"]))
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-2 * abs(float(z["loss"])), (float(loss.detach()), float(z["loss"]))
     g = mae.to_pixels.weight.grad.cpu().numpy()
     ref = z["grad/to_pixels.weight"]
     assert np.abs(g - ref).max() <= 0.1 * np.abs(ref).max()
@@ -133,7 +133,7 @@ def test_oracle_vit_tiny_shapes(dt, tol):
     cfg = O.OracleCfg(64, 32, 8, 4, 192, 3, 3, 768, 3, 2, 192, 2, 3, 0.75)
     P, r = _oracle_run(mae, cfg, x, noises)
     assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"]) and torch.equal(mae.last_mask[1].cpu(), r["unmasked_indices"])
-    assert abs(float(loss) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss), float(r["loss"]))
+    assert abs(float(loss.detach()) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss.detach()), float(r["loss"]))
     gtol = 2e-3 if dt == "fp32" else 0.15
     for name, p in mae.named_parameters():
         ref = P[name].grad
@@ -158,7 +158,7 @@ def test_vision_only_and_use_flags():
     P = {k: v.detach().cpu() for k, v in mae.state_dict().items()}
     with torch.no_grad():
         r = O.vtmae_forward(P, cfg, {k: v.cpu() for k, v in x.items()}, [n.cpu() for n in noise], use_tactile=False)
-    assert abs(float(loss) - float(r["loss"])) <= 1e-4 * abs(float(r["loss"]))
+    assert abs(float(loss.detach()) - float(r["loss"])) <= 1e-4 * abs(float(r["loss"]))
 
 
 def test_cfg2_full_size_properties():
@@ -197,9 +197,9 @@ def test_cfg2_full_size_properties():
     mae.zero_grad()
     loss2 = mae(x, mask_noise=noises)
     loss2.backward()
-    assert float(loss2) == float(loss) and torch.equal(mae.to_pixels.weight.grad, g1)
+    assert float(loss2) == float(loss.detach()) and torch.equal(mae.to_pixels.weight.grad, g1)
     # batch-permutation invariance of the mean loss (samples are independent)
     perm = torch.randperm(B, device=DEV)
     loss3 = mae({k: v[perm] for k, v in x.items()}, mask_noise=[n[perm] for n in noises])
-    assert abs(float(loss3) - float(loss)) <= 1e-3 * abs(float(loss))
+    assert abs(float(loss3) - float(loss.detach())) <= 1e-3 * abs(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in mae.parameters() if p.grad is not None)

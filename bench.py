@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MAE fwd+bwd samples/s (image + tactile) on N x MI355X — BASELINE.json configs[1] per GPU
+(VTT vision+tactile MAE: 64x64 RGB + 2x32x32 tactile, ViT-Tiny 192/12/3/768, decoder 192/4/3/768, mask 75 %,
+batch 256 per GPU, bf16 compute), synthetic random frames, random-init weights.
+
+One "step" = zero_grad + mask sampling + VTMAE forward + backward (+ RCCL gradient all-reduce when N > 1)
++ Adam(lr=1e-4) update (reference: models/ppo_mae.py:182-183,262-266).  Weak scaling: 256 samples per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed inside the
+timed region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+CFG2 = dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=192, depth=12, heads=3, mlp_dim=768,
+            dec_dim=192, dec_depth=4, dec_heads=3, ratio=0.75, num_tactiles=2)
+
+
+def fwd_flops_per_sample(c):
+    """SURVEY.md section 8(d) formula (forward; fwd+bwd = 3x)."""
+    def tf(n, D, depth, h, mlp):
+        hd = h * 64
+        return depth * (6 * n * D * hd + 4 * n * n * hd + 2 * n * hd * D + 4 * n * D * mlp)
+    n_img, n_tac = (c["image_size"] // c["image_patch_size"]) ** 2, (c["tactile_size"] // c["tactile_patch_size"]) ** 2
+    k = c["num_tactiles"]
+    N = n_img + k * n_tac
+    nmask = int(c["ratio"] * N)
+    nm_img = int(nmask * (n_img / N))
+    nm_tac = (nmask - nm_img) // k
+    nvis = N - nm_img - k * nm_tac
+    pd_i, pd_t = 3 * c["image_patch_size"] ** 2, 3 * c["tactile_patch_size"] ** 2
+    embed = 2 * (n_img - nm_img) * pd_i * c["dim"] + 2 * k * (n_tac - nm_tac) * pd_t * c["dim"]
+    heads = 2 * nm_img * c["dec_dim"] * pd_i + 2 * k * nm_tac * c["dec_dim"] * pd_t
+    return embed + tf(nvis, c["dim"], c["depth"], c["heads"], c["mlp_dim"]) + tf(N, c["dec_dim"], c["dec_depth"], c["dec_heads"], 4 * c["dec_dim"]) + heads
+
+
+def build_model(c, dtype, device):
+    from m3l_amd import VTMAE, VTT
+    torch.manual_seed(0)
+    enc = VTT(image_size=c["image_size"], tactile_size=c["tactile_size"], image_patch_size=c["image_patch_size"],
+              tactile_patch_size=c["tactile_patch_size"], dim=c["dim"], depth=c["depth"], heads=c["heads"], mlp_dim=c["mlp_dim"],
+              num_tactiles=c["num_tactiles"])
+    mae = VTMAE(encoder=enc, decoder_dim=c["dec_dim"], masking_ratio=c["ratio"], decoder_depth=c["dec_depth"],
+                decoder_heads=c["dec_heads"], num_tactiles=c["num_tactiles"], compute_dtype=dtype)
+    return mae.to(device)
+
+
+def cpu_baseline(c, seconds_budget=20.0):
+    """The CPU oracle (plain PyTorch fp32, autograd) on the same architecture: bounded sample, host cores of this box."""
+    from oracle import vtmae_oracle as O
+    torch.manual_seed(0)
+    mae = build_model(c, "fp32", "cpu")
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in mae.state_dict().items()}
+    cfg = O.OracleCfg(c["image_size"], c["tactile_size"], c["image_patch_size"], c["tactile_patch_size"], c["dim"], c["depth"],
+                      c["heads"], c["mlp_dim"], 3, c["num_tactiles"], c["dec_dim"], c["dec_depth"], c["dec_heads"], c["ratio"])
+    B = 64
+    g = torch.Generator().manual_seed(1234)
+    x = {"image": torch.rand(B, 3, c["image_size"], c["image_size"], generator=g)}
+    for i in range(c["num_tactiles"]):
+        x[f"tactile{i + 1}"] = torch.rand(B, 3, c["tactile_size"], c["tactile_size"], generator=g)
+    n_img, n_tac = (c["image_size"] // c["image_patch_size"]) ** 2, (c["tactile_size"] // c["tactile_patch_size"]) ** 2
+
+    def step():
+        noises = [torch.rand(B, n_img, generator=g)] + [torch.rand(B, n_tac, generator=g) for _ in range(c["num_tactiles"])]
+        for p in P.values():
+            p.grad = None
+        O.vtmae_forward(P, cfg, x, noises)["loss"].backward()
+    step()                                     # warm-up (allocator, thread pool)
+    t0, iters = time.perf_counter(), 0
+    while True:
+        step()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or iters >= 50:
+            break
+    return {"value": round(B * iters / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (oracle/vtmae_oracle.py, torch fp32 + autograd), cfg-2 model, B={B}, {iters} fwd+bwd iterations"
+                      f" in {el:.1f} s, {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default="", help="kernel-class substring to event-time inside the timed region ('' = all classes)")
+    ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: time fwd+bwd without the Adam update")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from m3l_amd import _lib
+    from m3l_amd.parallel import GradSync
+    _lib.lib()
+    c = CFG2
+    mae = build_model(c, args.dtype, dev)
+    sync = GradSync(mae)
+    opt = torch.optim.Adam(sync.params, lr=1e-4, fused=True)
+    B = args.batch
+    torch.manual_seed(1234 + rank)
+    x = {"image": torch.rand(B, 3, c["image_size"], c["image_size"], device=dev)}
+    for i in range(c["num_tactiles"]):
+        x[f"tactile{i + 1}"] = torch.rand(B, 3, c["tactile_size"], c["tactile_size"], device=dev)
+
+    def step():
+        sync.zero_grad()
+        loss = mae(x)                 # mask noise drawn on the device with torch.rand, as the reference does
+        loss.backward()
+        sync.finish()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.lib()
+    barrier()
+    lib.m3l_prof_begin(args.roofline_kernel.encode() if args.roofline_kernel else None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    el = time.perf_counter() - t0
+    lib.m3l_prof_end()
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = el / args.steps * 1e3
+    value = B * world * args.steps / el
+
+    out = {"metric": "MAE fwd+bwd samples/sec (image+tactile)", "value": round(value, 1), "unit": "samples/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: VTT vision+tactile MAE, 64x64 RGB + 2x32x32 tactile, ViT-Tiny "
+                                  "192/12/3/768 + decoder 192/4/3/768, mask 0.75",
+                      "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "step": "zero_grad + mask + fwd + bwd + grad all-reduce + Adam" if not args.no_optimizer else "fwd + bwd (diagnostic)"},
+           "loss": round(float(loss.detach()), 5)}
+    if rank == 0:
+        import ctypes as C
+        # ---- roofline of the dominant kernel class (HIP events recorded by the library inside the timed region)
+        n = lib.m3l_prof_count()
+        rows = []
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            ms_tot, launches, work = C.c_double(), C.c_long(), C.c_double()
+            lib.m3l_prof_get(i, name, 64, C.byref(ms_tot), C.byref(launches), C.byref(work))
+            if launches.value:
+                rows.append((name.value.decode(), ms_tot.value, launches.value, work.value))
+        rows.sort(key=lambda r: -r[1])
+        out["kernel_ms_per_step"] = {r[0]: round(r[1] / args.steps, 4) for r in rows}
+        if rows:
+            name, ms_tot, launches, work = rows[0]
+            avg_ms = ms_tot / launches
+            achieved = (work / launches) / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+                               "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                               "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": launches // args.steps}
+        total_flops = 3 * fwd_flops_per_sample(c) * value
+        out["model_tflops"] = round(total_flops / 1e12, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -285,6 +285,7 @@ int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, 
     M3L_CHECK(B > 0 && n > 0 && H > 0, "attn_fwd: empty problem B=%d n=%d H=%d", B, n, H);
     dim3 grid(cdiv(n, 64), B * H);
     const float scale = 0.125f;   // dim_head ** -0.5, dim_head = 64
+    ProfScope prof("attn_fwd", B, n, H, 4.0 * B * H * (double)n * n * 64, st);
     if (dtype == 1)
         attn_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)qkv, (bf16*)o, lse, n, H, scale);
     else
@@ -299,6 +300,7 @@ int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, cons
     M3L_CHECK(B > 0 && n > 0 && H > 0, "attn_bwd: empty problem B=%d n=%d H=%d", B, n, H);
     dim3 grid(cdiv(n, 64), B * H);
     const float scale = 0.125f;
+    ProfScope prof("attn_bwd", B, n, H, 10.0 * B * H * (double)n * n * 64, st);
     if (dtype == 1) {
         attn_bwd_dq_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)o, (const bf16*)dO, lse, dsum, (bf16*)dqkv, n, H, scale);
         attn_bwd_dkv_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dO, lse, dsum, (bf16*)dqkv, n, H, scale);

@@ -15,132 +15,194 @@ __device__ __forceinline__ void store_val(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_val(bf16* p, float v) { *p = (bf16)v; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm forward: y = (x - mean) * rstd * gamma + beta    (nn.LayerNorm, biased variance)
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta    (nn.LayerNorm, biased variance).  One wave per row, one
+// 16-byte chunk (4 floats) per lane and pass: D = 192 keeps 48 lanes busy with a single global_load_dwordx4.
+constexpr int MAXC = 4;           // float4 chunks per lane: rows up to 1024 wide, D % 4 == 0
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// row statistics of x[row] held in registers v[] (chunk i of this lane = elements 4*(lane+64 i) .. +3)
+__device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x4 (&v)[MAXC], float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int e = 4 * (lane + 64 * i);
+        v[i] = (e < D) ? load4(xr + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int e = 4 * (lane + 64 * i);
+        if (e < D) {
+            const f32x4 d = v[i] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, TO* __restrict__ y,
                                                        float* __restrict__ y32) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (long)row * D;
-    float v[MAXV];
-    float s = 0.f;
+    f32x4 v[MAXC];
+    float mean, rstd;
+    row_stats(x + (long)row * D, D, lane, v, eps, mean, rstd);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int e = lane + 64 * i;
-        v[i] = (e < D) ? xr[e] : 0.f;
-        s += v[i];
-    }
-    const float mean = wave_sum(s) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int e = lane + 64 * i;
-        const float d = (e < D) ? v[i] - mean : 0.f;
-        q += d * d;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int e = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int e = 4 * (lane + 64 * i);
         if (e < D) {
-            const float r = (v[i] - mean) * rstd * gamma[e] + beta[e];
-            if (y) store_val(y + (long)row * D + e, r);
-            if (y32) y32[(long)row * D + e] = r;
+            const f32x4 r = (v[i] - mean) * rstd * load4(gamma + e) + load4(beta + e);
+            if (y) store4<TO>(y + (long)row * D + e, r);
+            if (y32) store4<float>(y32 + (long)row * D + e, r);
         }
     }
 }
 
-// LayerNorm backward.  dx_out = (dres ? dres : 0) + dLN/dx ; per-block partial dgamma/dbeta -> part[G][2*D].
-template <typename TD>
+// LayerNorm backward.  dx_out = (dres ? dres : 0) + dLN/dx, optionally also stored in the compute type (dx_t_out: the
+// operand of the next dgrad / wgrad GEMM).  Per-block partials -> part[G][3*D]: dgamma | dbeta | column sums of dx_out
+// (= the bias gradient of the Linear whose output gradient dx_out is).
+template <typename TD, typename TC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, int M, int D,
                                                        const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
-                                                       float* __restrict__ dx_out, float* __restrict__ part) {
-    __shared__ float red[WPB][128];
+                                                       float* __restrict__ dx_out, TC* __restrict__ dx_t_out, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float red[WPB][3][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[MAXV], db[MAXV];
+    f32x4 dg[MAXC], db[MAXC], dc[MAXC];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) dg[i] = db[i] = 0.f;
+    for (int i = 0; i < MAXC; ++i) dg[i] = db[i] = dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
-        const float* xr = x + (long)row * D;
+        f32x4 v[MAXC], gdy[MAXC];
+        float mean, rstd;
+        row_stats(x + (long)row * D, D, lane, v, eps, mean, rstd);
         const TD* dyr = dy + (long)row * D;
-        float v[MAXV], gdy[MAXV];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int e = lane + 64 * i;
-            v[i] = (e < D) ? xr[e] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int e = lane + 64 * i;
-            const float d = (e < D) ? v[i] - mean : 0.f;
-            q += d * d;
-        }
-        const float rstd = rsqrtf(wave_sum(q) / D + eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int e = lane + 64 * i;
+        for (int i = 0; i < MAXC; ++i) {
+            const int e = 4 * (lane + 64 * i);
             if (e < D) {
-                const float xh = (v[i] - mean) * rstd;
-                const float d = to_f32(dyr[e]);
+                const f32x4 xh = (v[i] - mean) * rstd;
+                const f32x4 d = load4(dyr + e);
                 dg[i] += d * xh;
                 db[i] += d;
-                const float gd = d * gamma[e];
+                const f32x4 gd = d * load4(gamma + e);
                 gdy[i] = gd;
                 v[i] = xh;
-                s1 += gd;
-                s2 += gd * xh;
-            } else {
-                gdy[i] = 0.f;
-                v[i] = 0.f;
+                s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
+                const f32x4 t = gd * xh;
+                s2 += (t[0] + t[1]) + (t[2] + t[3]);
             }
         }
         s1 = wave_sum(s1) / D;
         s2 = wave_sum(s2) / D;
-        if (dx_out) {
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int e = lane + 64 * i;
-                if (e < D) {
-                    float r = rstd * (gdy[i] - s1 - v[i] * s2);
-                    if (dres) r += dres[(long)row * D + e];
-                    dx_out[(long)row * D + e] = r;
-                }
+        for (int i = 0; i < MAXC; ++i) {
+            const int e = 4 * (lane + 64 * i);
+            if (e < D) {
+                f32x4 r = (gdy[i] - s1 - v[i] * s2) * rstd;
+                if (dres) r += load4(dres + (long)row * D + e);
+                dc[i] += r;
+                if (dx_out) store4<float>(dx_out + (long)row * D + e, r);
+                if (dx_t_out) store4<TC>(dx_t_out + (long)row * D + e, r);
             }
         }
     }
-    // reduce the 4 waves' register partials through LDS in a fixed order, 64 columns at a time
-    float* out = part + (long)blockIdx.x * 2 * D;
+    // reduce the 4 waves' register partials through LDS in a fixed order, 256 columns at a time
+    float* out = part + (long)blockIdx.x * 3 * D;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        if (64 * i >= D) break;                 // uniform
-        red[wave][lane] = dg[i];
-        red[wave][64 + lane] = db[i];
+    for (int i = 0; i < MAXC; ++i) {
+        if (256 * i >= D) break;                 // uniform
+        *reinterpret_cast<f32x4*>(&red[wave][0][4 * lane]) = dg[i];
+        *reinterpret_cast<f32x4*>(&red[wave][1][4 * lane]) = db[i];
+        *reinterpret_cast<f32x4*>(&red[wave][2][4 * lane]) = dc[i];
         __syncthreads();
-        if (wave == 0) {
-            const int e = lane + 64 * i;
-            if (e < D) {
-                out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-                out[D + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
-            }
+        const int e = 256 * i + threadIdx.x;
+        if (e < D) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                out[k * D + e] = (red[0][k][threadIdx.x] + red[1][k][threadIdx.x]) + (red[2][k][threadIdx.x] + red[3][k][threadIdx.x]);
         }
         __syncthreads();
     }
 }
 
-// out[j] = (accumulate ? out[j] : 0) + sum_g part[g*stride + j],  j < count   (fixed summation order)
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int G, int stride, int count, float* __restrict__ out,
-                                   int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
+// out[j] = (accumulate ? out[j] : 0) + sum_g part[g*stride + j],  j < count.
+// 32 columns x 8 row-slices per 256-thread block; each slice sums its rows in a fixed order, then the 8 slices are
+// added in a fixed order through LDS -> bitwise reproducible, and G/8 independent loads per thread instead of G serial.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int G, int stride, int count,
+                                                            float* __restrict__ out, int accumulate) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(long)g * stride + j];
-    out[j] = accumulate ? out[j] + s : s;
+    if (j < count) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = sl;
+        for (; g + 24 < G; g += 32) {
+            s0 += part[(long)g * stride + j];
+            s1 += part[(long)(g + 8) * stride + j];
+            s2 += part[(long)(g + 16) * stride + j];
+            s3 += part[(long)(g + 24) * stride + j];
+        }
+        for (; g < G; g += 8) s0 += part[(long)g * stride + j];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && j < count) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i][cl];
+        out[j] = accumulate ? out[j] + t : t;
+    }
+}
+
+// up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment)
+struct ReduceSegs { float* out[4]; };
+__global__ __launch_bounds__(256) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
+                                                                ReduceSegs segs, int accumulate) {
+    __shared__ float red[8][33];
+    float* out = segs.out[blockIdx.y];
+    if (!out) return;                            // uniform per block
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cl;
+    const float* p = part + (long)blockIdx.y * width;
+    float s = 0.f;
+    if (j < width) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = sl;
+        for (; g + 24 < G; g += 32) {
+            s0 += p[(long)g * stride + j];
+            s1 += p[(long)(g + 8) * stride + j];
+            s2 += p[(long)(g + 16) * stride + j];
+            s3 += p[(long)(g + 24) * stride + j];
+        }
+        for (; g < G; g += 8) s0 += p[(long)g * stride + j];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && j < width) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i][cl];
+        out[j] = accumulate ? out[j] + t : t;
+    }
 }
 
 // column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, rows strided by grid
@@ -572,7 +634,8 @@ static int part_grid(long rows) {
 
 int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y, float* y32,
                hipStream_t st) {
-    M3L_CHECK(M > 0 && D > 0 && D <= 64 * MAXV, "ln_fwd: bad shape M=%d D=%d", M, D);
+    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "ln_fwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
+    ProfScope prof("ln_fwd", M, D, out_dtype, (double)M * D * (4.0 + (y ? (out_dtype ? 2 : 4) : 0) + (y32 ? 4 : 0)), st);
     if (out_dtype == 1)
         ln_fwd_kernel<bf16><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (bf16*)y, y32);
     else
@@ -582,23 +645,31 @@ int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, 
 }
 
 int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st) {
-    reduce_rows_kernel<<<cdiv(count, 256), 256, 0, st>>>(part, G, stride, count, out, accumulate);
+    reduce_rows_kernel<<<cdiv(count, 32), 256, 0, st>>>(part, G, stride, count, out, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
 
 int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
-               float* dx_out, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
-    M3L_CHECK(M > 0 && D > 0 && D <= 64 * MAXV, "ln_bwd: bad shape M=%d D=%d", M, D);
-    const int G = part_grid(M);
-    if (dy_dtype == 1)
-        ln_bwd_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)dy, x, M, D, gamma, eps, dres, dx_out, part_ws);
-    else
-        ln_bwd_kernel<float><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, part_ws);
+               float* dx_out, void* dx_t_out, int ct_dtype, float* part_ws, float* dgamma, float* dbeta, float* dbias,
+               int accumulate, hipStream_t st) {
+    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "ln_bwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
+    int G = cdiv(M, 2 * WPB);                    // >= 2 rows per wave; 8 workgroups per CU keep the HBM pipe full
+    if (G > 2048) G = 2048;
+    if (G < 1) G = 1;
+    {
+        ProfScope prof("ln_bwd", M, D, dy_dtype,
+                       (double)M * D * (4.0 + (dy_dtype ? 2 : 4) + (dres ? 4 : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
+        if (dy_dtype == 1)
+            ln_bwd_kernel<bf16, bf16><<<G, 256, 0, st>>>((const bf16*)dy, x, M, D, gamma, eps, dres, dx_out, (bf16*)dx_t_out, part_ws);
+        else if (ct_dtype == 1)
+            ln_bwd_kernel<float, bf16><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, (bf16*)dx_t_out, part_ws);
+        else
+            ln_bwd_kernel<float, float><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, (float*)dx_t_out, part_ws);
+    }
     M3L_LAUNCH_CHECK();
-    // part rows are [dgamma(D) | dbeta(D)]; dgamma and dbeta live in different tensors
-    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws, G, 2 * D, D, dgamma, accumulate);
-    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws + D, G, 2 * D, D, dbeta, accumulate);
+    ReduceSegs segs = {{dgamma, dbeta, dbias, nullptr}};
+    reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 3), 256, 0, st>>>(part_ws, G, 3 * D, D, segs, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -609,6 +680,7 @@ int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, f
     if (G > M3L_MAX_PARTIAL_BLOCKS) G = M3L_MAX_PARTIAL_BLOCKS;
     const int rpb = cdiv(M, G);
     G = cdiv(M, rpb);
+    ProfScope prof("colsum", M, N, dtype, (double)M * N * (dtype ? 2 : 4), st);
     if (dtype == 1)
         colsum_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)Y, M, N, ld, rpb, part_ws);
     else
@@ -619,6 +691,7 @@ int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, f
 
 int m3l_prep_weights(int dtype, const WeightPack* pack, hipStream_t st) {
     if (pack->count <= 0) return 0;
+    ProfScope prof("prep_weights", pack->count, dtype, 0, 0.0, st);
     dim3 grid(64, pack->count);
     if (dtype == 1)
         prep_weights_kernel<bf16><<<grid, 256, 0, st>>>(*pack);
@@ -638,6 +711,7 @@ int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out,
 }
 
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st) {
+    ProfScope prof("cast", count, dtype, 0, (double)count * (4.0 + (dtype ? 2 : 4)), st);
     if (dtype == 1)
         cast_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>(x, count, (bf16*)out);
     else
@@ -717,8 +791,8 @@ int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int id
     else
         patch_ln_bwd_kernel<float><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const float*)dxn, pdpad, part_ws);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(pd, 256), 256, 0, st>>>(part_ws, G, 2 * pd, pd, dgamma, accumulate);
-    reduce_rows_kernel<<<cdiv(pd, 256), 256, 0, st>>>(part_ws + pd, G, 2 * pd, pd, dbeta, accumulate);
+    reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws, G, 2 * pd, pd, dgamma, accumulate);
+    reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws + pd, G, 2 * pd, pd, dbeta, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -747,9 +821,9 @@ int m3l_embed_finalize_bwd(int dtype, const float* dtok, int L, const float* E, 
     else
         embed_finalize_bwd_kernel<float><<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, L, E, rows, D, *pg, idx, idx_ld, j0, cnt, gamma, eps, (float*)dE, part_ws, nslot);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws, G, PL, D, dgamma, accumulate);
-    reduce_rows_kernel<<<cdiv(D, 256), 256, 0, st>>>(part_ws + D, G, PL, D, dbeta, accumulate);
-    reduce_rows_kernel<<<cdiv(nslot * D, 256), 256, 0, st>>>(part_ws + 2 * D, G, PL, nslot * D, dmod + (long)mod0 * D, accumulate);
+    reduce_rows_kernel<<<cdiv(D, 32), 256, 0, st>>>(part_ws, G, PL, D, dgamma, accumulate);
+    reduce_rows_kernel<<<cdiv(D, 32), 256, 0, st>>>(part_ws + D, G, PL, D, dbeta, accumulate);
+    reduce_rows_kernel<<<cdiv(nslot * D, 32), 256, 0, st>>>(part_ws + 2 * D, G, PL, nslot * D, dmod + (long)mod0 * D, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -773,8 +847,8 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
     unshuffle_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dY, unmasked, nvis, masked, nmask, B, dd, n_img, n_tac > 0 ? n_tac : 1,
                                                              nmod, dsrc, part_ws);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(dd, 256), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
-    reduce_rows_kernel<<<cdiv(nmod * dd, 256), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
+    reduce_rows_kernel<<<cdiv(dd, 32), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
+    reduce_rows_kernel<<<cdiv(nmod * dd, 32), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -36,25 +36,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     auto As = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st) * NT_STAGE_BYTES); };
     auto Bs = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st + 1) * NT_STAGE_BYTES); };
 
-    uint4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
-            const int k = k0 + cc * EPC;
-            const uint4 z = {0u, 0u, 0u, 0u};
-            ra[i] = (m0 + row < M && k < K) ? *reinterpret_cast<const uint4*>(A + (long)(m0 + row) * lda + k) : z;
-            rb[i] = (n0 + row < N && k < K) ? *reinterpret_cast<const uint4*>(W + (long)(n0 + row) * ldw + k) : z;
-        }
-    };
-    auto swrite = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(As(st)) + row * 144 + cc * 16) = ra[i];
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Bs(st)) + row * 144 + cc * 16) = rb[i];
-        }
-    };
+    // register staging (named registers + macros: lambdas capturing the arrays pushed them to scratch)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+#define NT_GLOAD1(i, RA, RB, k0)                                                                              \
+    {                                                                                                         \
+        const int c = tid + 256 * (i), row = c >> 3, cc = c & 7;                                             \
+        const int k = (k0) + cc * EPC;                                                                        \
+        RA = (m0 + row < M && k < K) ? *reinterpret_cast<const uint4*>(A + (long)(m0 + row) * lda + k) : zero4; \
+        RB = (n0 + row < N && k < K) ? *reinterpret_cast<const uint4*>(W + (long)(n0 + row) * ldw + k) : zero4; \
+    }
+#define NT_GLOAD(k0) NT_GLOAD1(0, ra0, rb0, k0) NT_GLOAD1(1, ra1, rb1, k0) NT_GLOAD1(2, ra2, rb2, k0) NT_GLOAD1(3, ra3, rb3, k0)
+#define NT_SWRITE1(i, RA, RB, st)                                                                             \
+    {                                                                                                         \
+        const int c = tid + 256 * (i), row = c >> 3, cc = c & 7;                                             \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(As(st)) + row * 144 + cc * 16) = RA;               \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Bs(st)) + row * 144 + cc * 16) = RB;               \
+    }
+#define NT_SWRITE(st) NT_SWRITE1(0, ra0, rb0, st) NT_SWRITE1(1, ra1, rb1, st) NT_SWRITE1(2, ra2, rb2, st) NT_SWRITE1(3, ra3, rb3, st)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -63,12 +62,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + C::BK - 1) / C::BK;
-    gload(0);
-    swrite(0);
+    NT_GLOAD(0)
+    NT_SWRITE(0)
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) gload((t + 1) * C::BK);
+        if (t + 1 < nk) { NT_GLOAD((t + 1) * C::BK) }
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
             Frag<T> fa[4], fb[4];
@@ -82,9 +81,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
         }
-        if (t + 1 < nk) swrite(cur ^ 1);
+        if (t + 1 < nk) { NT_SWRITE(cur ^ 1) }
         __syncthreads();
     }
+#undef NT_GLOAD
+#undef NT_GLOAD1
+#undef NT_SWRITE
+#undef NT_SWRITE1
 
     // ---- epilogue: accumulators -> LDS (f32) -> 16-byte row segments ---------------------------------------
     float* Cs = reinterpret_cast<float*>(smem);
@@ -150,6 +153,203 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// gemm_nt, main path: LDS-DMA staging (global_load_lds_dwordx4, no VGPR round trip), unpadded 128-byte LDS rows with the
+// 16-byte chunk index XOR-ed by (row & 7) — applied on the per-lane SOURCE address (the DMA destination is lane-linear)
+// and again on the fragment read (guide rule 21) -> conflict-free ds_read_b128.  Two stages; the next K-tile's DMA is
+// issued before the MFMA block of the current one.  Needs K % (128 / sizeof(T)) == 0; rows past M / N are clamped (their
+// products are never stored).
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                             int M, int N, int K, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = Chunk<T>::N;             // elements per 16-byte chunk
+    constexpr int BKE = 8 * EPC;                 // elements per 128-byte LDS row (K-tile depth): 64 bf16 / 32 f32
+    constexpr int KSTEPS = BKE / 32;             // MFMA macro steps per K-tile
+    constexpr int A_BYTES = 128 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = (BN == 128) ? 64 : 32;    // rows per wave: 2x2 waves of 64x64, or 4x1 waves of 32x64
+    constexpr int TM = WM / 16;
+    constexpr int CSLD = BN + 4;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* gl_vp;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int wr = (BN == 128) ? (wave >> 1) : wave, wc = (BN == 128) ? (wave & 1) : 0;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
+
+    // per-lane source pointers of this wave's DMA segments (1 KiB = 8 rows x 8 chunks each)
+    const int srow = lane >> 3, spc = lane & 7;
+    const T* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + srow;
+        asrc[i] = A + (long)min(m0 + row, M - 1) * lda + (spc ^ (row & 7)) * EPC;
+    }
+    constexpr int BSEG = BN / 32;                // B segments per wave: 4 (BN=128) or 2 (BN=64)
+    const T* bsrc[BSEG];
+#pragma unroll
+    for (int i = 0; i < BSEG; ++i) {
+        const int row = (wave * BSEG + i) * 8 + srow;
+        bsrc[i] = W + (long)min(n0 + row, N - 1) * ldw + (spc ^ (row & 7)) * EPC;
+    }
+    auto stage = [&](int st, int k0) {
+        char* base = smem + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gl_vp)(asrc[i] + k0), (lds_vp)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BSEG; ++i)
+            __builtin_amdgcn_global_load_lds((gl_vp)(bsrc[i] + k0), (lds_vp)(base + A_BYTES + (wave * BSEG + i) * 1024), 16, 0, 0);
+    };
+    // fragment of macro step ks for LDS row `row` of a tile at `base`
+    auto frag = [&](const char* base, int row, int ks) {
+        Frag<T> f;
+        if constexpr (sizeof(T) == 2) {
+            f.v = *reinterpret_cast<const bf16x8*>(base + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4));
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + row * 128 + (((2 * g) ^ (row & 7)) << 4));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(base + row * 128 + (((2 * g + 1) ^ (row & 7)) << 4));
+            f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+            f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+        }
+        return f;
+    };
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BKE;
+    stage(0, 0);
+    __syncthreads();                               // vmcnt(0) + barrier: tile 0 landed for every wave
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BKE);
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> fa[TM], fb[4];
+#pragma unroll
+            for (int x = 0; x < TM; ++x) fa[x] = frag(As, wr * WM + x * 16 + li, ks);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) fb[y] = frag(Bs, wc * 64 + y * 16 + li, ks);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+        }
+        __syncthreads();                           // next tile landed (vmcnt(0)) and this one fully read
+    }
+
+    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte row segments -----------------------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wr * WM + a * 16 + 4 * g + r) * CSLD + wc * 64 + b * 16 + li] = acc[a][b][r];
+    __syncthreads();
+
+    constexpr int CPR = BN / 8, RSTEP = 256 / CPR, ITERS = 128 / RSTEP;
+    const int cchunk = tid % CPR, r0 = tid / CPR;
+    const int col = n0 + cchunk * 8;
+    const bool col_ok = col < N;
+    float bias[8], csum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bias[j] = (epi.bias && col_ok && col + j < epi.n_bias) ? epi.bias[col + j] : 0.f;
+        csum[j] = 0.f;
+    }
+    T* out_t = reinterpret_cast<T*>(epi.out_t);
+    T* out_pre = reinterpret_cast<T*>(epi.out_pre);
+    const T* gelu_u = reinterpret_cast<const T*>(epi.gelu_u);
+    if (col_ok) {
+#pragma unroll 2
+        for (int i = 0; i < ITERS; ++i) {
+            const int rl = r0 + RSTEP * i, row = m0 + rl;
+            if (row >= M) break;
+            float v[8];
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(Cs + rl * CSLD + cchunk * 8);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(Cs + rl * CSLD + cchunk * 8 + 4);
+            v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3];
+            v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
+            const long o = (long)row * epi.ldc + col;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * epi.alpha + bias[j];
+            if (gelu_u) {
+                Frag<T> uu;
+                if constexpr (sizeof(T) == 2) {
+                    uu.v = *reinterpret_cast<const bf16x8*>(gelu_u + o);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) uu.v[j] = gelu_u[o + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(to_f32(uu.v[j]));
+            }
+            if (out_pre) {
+                Frag<T> pk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pk.v[j] = from_f32<T>(v[j]);
+                    v[j] = to_f32(pk.v[j]);
+                }
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<bf16x8*>(out_pre + o) = pk.v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out_pre[o + j] = pk.v[j];
+                }
+            }
+            if (epi.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            }
+            if (epi.res) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(epi.res + o);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(epi.res + o + 4);
+                v[0] += q0[0]; v[1] += q0[1]; v[2] += q0[2]; v[3] += q0[3];
+                v[4] += q1[0]; v[5] += q1[1]; v[6] += q1[2]; v[7] += q1[3];
+            }
+            if (epi.out_f32) {
+                *reinterpret_cast<f32x4*>(epi.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(epi.out_f32 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            if (out_t) {
+                Frag<T> pk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pk.v[j] = from_f32<T>(v[j]);
+                    csum[j] += to_f32(pk.v[j]);
+                }
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<bf16x8*>(out_t + o) = pk.v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out_t[o + j] = pk.v[j];
+                }
+            }
+        }
+    }
+    if (epi.colsum_part) {
+        // column sums of the compute-type output over this workgroup's rows -> part[blockIdx.y][N] (fixed order)
+        float* red = reinterpret_cast<float*>(smem) + 128 * CSLD;     // [RSTEP][BN]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[r0 * BN + cchunk * 8 + j] = csum[j];
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float s = 0.f;
+            for (int r = 0; r < RSTEP; ++r) s += red[r * BN + tid];
+            epi.colsum_part[(long)blockIdx.y * N + n0 + tid] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16> { static constexpr int BMT = 64, MS = 2, ROW = 144, CPR = 16; };   // 288-byte rows
 template <> struct TnCfg<float> { static constexpr int BMT = 32, MS = 1, ROW = 132, CPR = 32; };  // 528-byte rows
@@ -171,25 +371,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, i
     auto Ys = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st) * TN_STAGE_BYTES); };
     auto Xs = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st + 1) * TN_STAGE_BYTES); };
 
-    uint4 ry[4], rx[4];
-    auto gload = [&](int mb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c / C::CPR, cc = c % C::CPR;
-            const int m = mb + row;
-            const uint4 z = {0u, 0u, 0u, 0u};
-            ry[i] = (m < m_end && n0 + cc * EPC < N) ? *reinterpret_cast<const uint4*>(Y + (long)m * ldy + n0 + cc * EPC) : z;
-            rx[i] = (m < m_end && k0 + cc * EPC < K) ? *reinterpret_cast<const uint4*>(X + (long)m * ldx + k0 + cc * EPC) : z;
-        }
-    };
-    auto swrite = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c / C::CPR, cc = c % C::CPR;
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Ys(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = ry[i];
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Xs(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = rx[i];
-        }
-    };
+    uint4 ry0, ry1, ry2, ry3, rx0, rx1, rx2, rx3;
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+#define TN_GLOAD1(i, RY, RX, mb)                                                                                              \
+    {                                                                                                                         \
+        const int c = tid + 256 * (i), row = c / C::CPR, cc = c % C::CPR;                                                    \
+        const int m = (mb) + row;                                                                                             \
+        RY = (m < m_end && n0 + cc * EPC < N) ? *reinterpret_cast<const uint4*>(Y + (long)m * ldy + n0 + cc * EPC) : zero4;   \
+        RX = (m < m_end && k0 + cc * EPC < K) ? *reinterpret_cast<const uint4*>(X + (long)m * ldx + k0 + cc * EPC) : zero4;   \
+    }
+#define TN_GLOAD(mb) TN_GLOAD1(0, ry0, rx0, mb) TN_GLOAD1(1, ry1, rx1, mb) TN_GLOAD1(2, ry2, rx2, mb) TN_GLOAD1(3, ry3, rx3, mb)
+#define TN_SWRITE1(i, RY, RX, st)                                                                                             \
+    {                                                                                                                         \
+        const int c = tid + 256 * (i), row = c / C::CPR, cc = c % C::CPR;                                                    \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Ys(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = RY;         \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Xs(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = RX;         \
+    }
+#define TN_SWRITE(st) TN_SWRITE1(0, ry0, rx0, st) TN_SWRITE1(1, ry1, rx1, st) TN_SWRITE1(2, ry2, rx2, st) TN_SWRITE1(3, ry3, rx3, st)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -199,13 +397,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, i
 
     const int nt = (m_end - m_beg + C::BMT - 1) / C::BMT;
     if (nt > 0) {
-        gload(m_beg);
-        swrite(0);
+        TN_GLOAD(m_beg)
+        TN_SWRITE(0)
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) gload(m_beg + (t + 1) * C::BMT);
+        if (t + 1 < nt) { TN_GLOAD(m_beg + (t + 1) * C::BMT) }
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) {
             Frag<T> fa[4], fb[4];
@@ -219,9 +417,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, i
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
         }
-        if (t + 1 < nt) swrite(cur ^ 1);
+        if (t + 1 < nt) { TN_SWRITE(cur ^ 1) }
         __syncthreads();
     }
+#undef TN_GLOAD
+#undef TN_GLOAD1
+#undef TN_SWRITE
+#undef TN_SWRITE1
     float* P = partial + (long)sp * N * K;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -248,11 +450,19 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int S, i
 
 }  // namespace
 
+static constexpr int glds_lds_bytes(int bn) {
+    const int stages = 2 * (128 * 128 + bn * 128), cs = 128 * (bn + 4) * 4;
+    return (stages > cs ? stages : cs) + (256 / (bn / 8)) * bn * 4;
+}
 static int g_gemm_inited = 0;
 int m3l_gemm_init() {
     if (g_gemm_inited) return 0;
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_gemm_inited = 1;
@@ -269,14 +479,35 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
     M3L_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && epi->ldc % 8 == 0,
               "gemm_nt: K,N,lda,ldw,ldc must be multiples of 8 (got K=%d N=%d lda=%d ldw=%d ldc=%d)", K, N, lda, ldw, epi->ldc);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM));
-    if (dtype == 1)
-        gemm_nt_kernel<bf16><<<grid, 256, NT_LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
-    else
-        gemm_nt_kernel<float><<<grid, 256, NT_LDS_BYTES, st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+    ProfScope prof("gemm_nt", M, N, K, 2.0 * M * N * K, st);
+    const int bke = dtype == 1 ? 64 : 32;
+    if (K % bke == 0) {
+        if (N % 128 == 0 || N >= 1024) {
+            dim3 grid(cdiv(N, 128), cdiv(M, 128));
+            if (dtype == 1)
+                gemm_nt_glds_kernel<bf16, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+            else
+                gemm_nt_glds_kernel<float, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+        } else {
+            dim3 grid(cdiv(N, 64), cdiv(M, 128));
+            if (dtype == 1)
+                gemm_nt_glds_kernel<bf16, 64><<<grid, 256, glds_lds_bytes(64), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+            else
+                gemm_nt_glds_kernel<float, 64><<<grid, 256, glds_lds_bytes(64), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+        }
+    } else {
+        M3L_CHECK(epi->colsum_part == nullptr, "gemm_nt: colsum epilogue needs K %% %d == 0", bke);
+        dim3 grid(cdiv(N, BN), cdiv(M, BM));
+        if (dtype == 1)
+            gemm_nt_kernel<bf16><<<grid, 256, NT_LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+        else
+            gemm_nt_kernel<float><<<grid, 256, NT_LDS_BYTES, st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+    }
     M3L_LAUNCH_CHECK();
     return 0;
 }
+
+int m3l_gemm_nt_colsum_rows(int M) { return cdiv(M, 128); }
 
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
     const int tiles = cdiv(N, 128) * cdiv(K, 128);
@@ -301,11 +532,15 @@ int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M
     int mps = cdiv(cdiv(M, S), unit) * unit;
     S = cdiv(M, mps);
     dim3 grid(cdiv(N, 128), cdiv(K, 128), S);
+    {
+    ProfScope prof("gemm_tn", M, N, K, 2.0 * M * N * K, st);
     if (dtype == 1)
         gemm_tn_kernel<bf16><<<grid, 256, TN_LDS_BYTES, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, partial_ws);
     else
         gemm_tn_kernel<float><<<grid, 256, TN_LDS_BYTES, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, partial_ws);
+    }
     M3L_LAUNCH_CHECK();
+    ProfScope prof2("gemm_tn_reduce", S, N, K, (double)S * N * K * 4.0, st);
     const long cnt = (long)N * K;
     reduce_splits_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(partial_ws, S, N, K, out, ldo, nvalid, kvalid, accumulate);
     M3L_LAUNCH_CHECK();

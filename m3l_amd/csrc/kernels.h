@@ -11,6 +11,14 @@
 
 // dtype codes: 0 = f32, 1 = bf16
 
+// RAII HIP-event bracket around one launch (prof.hip); a no-op unless m3l_prof_begin() is active.
+struct ProfScope {
+    int idx;
+    hipStream_t stream;
+    ProfScope(const char* kind, long a, long b, long c, double work, hipStream_t st);
+    ~ProfScope();
+};
+
 struct GemmEpi {
     const float* bias;     // [N] or null
     const float* res;      // f32 [M, ldc] residual added last, or null
@@ -22,6 +30,7 @@ struct GemmEpi {
     int ldc;
     float alpha;
     int n_bias;            // bias has n_bias valid entries (columns beyond read as 0); 0 -> N
+    float* colsum_part;    // [cdiv(M,128), N] per-row-block column sums of out_t (bias gradient fused into a dgrad) or null
 };
 
 struct WeightDesc {
@@ -48,6 +57,7 @@ size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);
 int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws, size_t ws_bytes,
                 float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st);
 int m3l_gemm_init();
+int m3l_gemm_nt_colsum_rows(int M);   // number of partial rows written through GemmEpi::colsum_part
 
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
@@ -55,8 +65,10 @@ int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, cons
 
 int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y, float* y32,
                hipStream_t st);
+// dx_out (f32) and/or dx_t_out (compute type ct_dtype) = dres + dLN/dx; dbias (optional) = column sums of that result
 int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
-               float* dx_out, float* part_ws, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+               float* dx_out, void* dx_t_out, int ct_dtype, float* part_ws, float* dgamma, float* dbeta, float* dbias, int accumulate,
+               hipStream_t st);
 int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st);
 int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st);
 int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);

@@ -43,7 +43,7 @@ inline size_t esz(int dtype) { return dtype ? 2 : 4; }
 
 // scratch big enough for every reduction / split-K slab of one module
 size_t scratch_bytes(int M, const std::vector<std::pair<int, int>>& wshapes, int maxcols) {
-    size_t s = (size_t)M3L_MAX_PARTIAL_BLOCKS * 4 * (size_t)maxcols * sizeof(float);
+    size_t s = (size_t)2048 * 4 * (size_t)maxcols * sizeof(float);
     for (auto& nk : wshapes) s = std::max(s, m3l_gemm_tn_ws_bytes(M, nk.first, nk.second, nullptr));
     return s;
 }
@@ -125,6 +125,7 @@ struct TfWs {
     void *dx_t, *du, *dxn, *d_o, *dqkv;
     float* dsum;
     float* scratch;
+    float* scratch2;      // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue
     size_t scratch_b;
     size_t total;
 };
@@ -158,6 +159,7 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
     w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.scratch2 = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
     w.total = a.off + 256;
     return w;
 }
@@ -167,6 +169,7 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
     M3L_CHECK(c->mlp_dim > 0 && c->mlp_dim % 8 == 0, "transformer: mlp_dim=%d must be a multiple of 8", c->mlp_dim);
     M3L_CHECK(c->heads > 0 && c->depth >= 0, "transformer: heads=%d depth=%d", c->heads, c->depth);
     M3L_CHECK(c->project_out || c->heads * 64 == c->dim, "transformer: identity to_out needs heads*64 == dim");
+    M3L_CHECK(c->dim % 64 == 0, "transformer: dim=%d must be a multiple of 64 (LDS-DMA GEMM K-tile)", c->dim);
     M3L_CHECK(B > 0 && n > 0, "transformer: empty input B=%d n=%d", B, n);
     return 0;
 }
@@ -388,34 +391,38 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     const float* x_last = c->depth ? w.L[c->depth - 1].xout : x_in;
     const void* const* tf = tensors + 11 * c->depth;
     float* const* gf = grads + 11 * c->depth;
-    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, w.scratch, gf[0], gf[1], 0, st)) return 1;
+    // every ln_bwd also emits its result in the compute type (operand of the next GEMMs) and the column sums of it
+    // (= bias gradient of the Linear that produced the residual branch): no separate cast / colsum passes.
+    float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;       // fc2 bias of the last layer
+    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, w.dx_t, dt, w.scratch, gf[0], gf[1], db_last, 0, st))
+        return 1;
+    const int csrows = m3l_gemm_nt_colsum_rows(M);
     for (int l = c->depth - 1; l >= 0; --l) {
         TfLayer& L = w.L[l];
         const float* xl = l ? w.L[l - 1].xout : x_in;
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
-        if (m3l_cast_f32(dt, w.dx, (long)M * D, w.dx_t, st)) return 1;
         GemmEpi e = epi0(mlp);
-        e.out_t = w.du; e.gelu_u = L.u;
+        e.out_t = w.du; e.gelu_u = L.u; e.colsum_part = w.scratch2;
         if (m3l_gemm_nt(dt, w.dx_t, D, L.w2T, D, M, mlp, D, &e, st)) return 1;                        // du = (dx W2) * gelu'(u)
+        if (m3l_reduce_rows(w.scratch2, csrows, mlp, mlp, g[8], 0, st)) return 1;                     // fc1 bias grad
         if (m3l_gemm_tn(dt, w.dx_t, D, L.h, mlp, M, D, mlp, w.scratch, w.scratch_b, g[9], mlp, D, mlp, 0, st)) return 1;
-        if (m3l_colsum(0, w.dx, M, D, D, w.scratch, g[10], 0, st)) return 1;
         e = epi0(D);
         e.out_t = w.dxn;
         if (m3l_gemm_nt(dt, w.du, mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                      // dxn2 = du W1
         if (m3l_gemm_tn(dt, w.du, mlp, L.xn2, D, M, mlp, D, w.scratch, w.scratch_b, g[7], D, mlp, D, 0, st)) return 1;
-        if (m3l_colsum(dt, w.du, M, mlp, mlp, w.scratch, g[8], 0, st)) return 1;
-        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.scratch, g[5], g[6], 0, st)) return 1;   // dx1 (in place)
+        // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
+        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx_t, dt, w.scratch, g[5], g[6],
+                       c->project_out ? g[4] : nullptr, 0, st))
+            return 1;
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
         const void* d_o = w.dx_t;
-        if (m3l_cast_f32(dt, w.dx, (long)M * D, w.dx_t, st)) return 1;
         if (c->project_out) {
             e = epi0(HD);
             e.out_t = w.d_o;
             if (m3l_gemm_nt(dt, w.dx_t, D, L.woT, D, M, HD, D, &e, st)) return 1;                     // do = dx1 Wo
             if (m3l_gemm_tn(dt, w.dx_t, D, L.o, HD, M, D, HD, w.scratch, w.scratch_b, g[3], HD, D, HD, 0, st)) return 1;
-            if (m3l_colsum(0, w.dx, M, D, D, w.scratch, g[4], 0, st)) return 1;
             d_o = w.d_o;
         }
         if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv, B, n, c->heads, st)) return 1;
@@ -424,7 +431,10 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         if (m3l_gemm_nt(dt, w.dqkv, 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;         // dxn1 = dqkv Wqkv
         if (m3l_gemm_tn(dt, w.dqkv, 3 * HD, L.xn1, D, M, 3 * HD, D, w.scratch, w.scratch_b, g[2], D, 3 * HD, D, 0, st)) return 1;
         float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
-        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, w.scratch, g[0], g[1], 0, st)) return 1;
+        float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
+        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t : nullptr, dt, w.scratch, g[0], g[1],
+                       db_prev, 0, st))
+            return 1;
     }
     if (c->depth == 0 && dx_in) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
@@ -632,7 +642,7 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
 
 // ---------------------------------------------------------------------------------------------------------------
 // stand-alone ops
-size_t m3l_layernorm_ws_bytes(int D) { return (size_t)M3L_MAX_PARTIAL_BLOCKS * 2 * D * sizeof(float) + 256; }
+size_t m3l_layernorm_ws_bytes(int D) { return (size_t)2048 * 3 * D * sizeof(float) + 256; }
 
 int m3l_layernorm_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y,
                       float* y32, void* stream) {
@@ -640,7 +650,7 @@ int m3l_layernorm_fwd(int out_dtype, const float* x, int M, int D, const float* 
 }
 int m3l_layernorm_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
                       float* dx, void* ws, float* dgamma, float* dbeta, void* stream) {
-    return m3l_ln_bwd(dy_dtype, dy, x, M, D, gamma, eps, dres, dx, (float*)ws, dgamma, dbeta, 0, (hipStream_t)stream);
+    return m3l_ln_bwd(dy_dtype, dy, x, M, D, gamma, eps, dres, dx, nullptr, dy_dtype, (float*)ws, dgamma, dbeta, nullptr, 0, (hipStream_t)stream);
 }
 int m3l_gather_tokens(const float* src, int B, int N, int D, const int64_t* idx, int K, float* dst, void* stream) {
     return m3l_gather_rows(0, src, N, D, idx, K, 0, K, B, dst, (hipStream_t)stream);

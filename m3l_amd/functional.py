@@ -72,12 +72,38 @@ def mask_sample(geom: L.Geom, ratio: float, noises):
     return masked, unmasked, c
 
 
+def _grad_targets(sink, params, used=None):
+    """Where the native backward writes parameter gradients.
+    sink None  -> fresh zero tensors, returned to autograd (which accumulates into .grad: reference semantics).
+    sink given -> (GradSync, bucket): the parameters' .grad are views into the sync's flat buffer; the kernels write
+                  them in place (overwrite) and autograd gets None for them (no per-tensor accumulate / copy kernels)."""
+    out = []
+    for i, p in enumerate(params):
+        ok = p is not None and (used is None or used[i])
+        if not ok:
+            out.append(None)
+        elif sink is not None and getattr(p, "grad", None) is not None and p.requires_grad:
+            out.append(p.grad)
+        else:
+            out.append(torch.zeros_like(p))
+    return out
+
+
+def _returned(sink, grads):
+    return tuple(None for _ in grads) if sink is not None else tuple(grads)
+
+
+def _done(sink):
+    if sink is not None:
+        sink[0].bucket_done(sink[1])
+
+
 # -------------------------------------------------------------------------------------------------------------------
 class EmbedFn(torch.autograd.Function):
     """inputs: image / tactile tensors (no grad), then the 15 tensors of the embed group (see header)."""
 
     @staticmethod
-    def forward(ctx, geom, D, dt, idx, cnt_img, L_tok, image, tactiles, *tensors):
+    def forward(ctx, sink, geom, D, dt, idx, cnt_img, L_tok, image, tactiles, *tensors):
         ref = image if image is not None else tactiles[0]
         _require_cuda(ref, "MAE input")
         B, dev = ref.shape[0], ref.device
@@ -90,7 +116,7 @@ class EmbedFn(torch.autograd.Function):
         L.check(L.lib().m3l_embed_fwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image), tac_arr,
                                       L.ptr_array(tens), L.ptr(ws), L.ptr(tokens), _stream()), "m3l_embed_fwd")
         ctx.saved = (geom, D, dt, idx, cnt_img, L_tok, image, tactiles, tens, ws)
-        ctx.n_t = len(tensors)
+        ctx.params, ctx.sink = tensors, sink
         return tokens
 
     @staticmethod
@@ -99,12 +125,13 @@ class EmbedFn(torch.autograd.Function):
         B = dtokens.shape[0]
         dtokens = _f32c(dtokens)
         # parameters of a modality that is absent from this call stay without gradient (as in the reference graph)
-        used = [image is not None] * 6 + [len(tactiles) > 0] * 6 + [True]
-        grads = [torch.zeros_like(t) if (t is not None and i < 13 and used[i]) else None for i, t in enumerate(tens)]
+        used = [image is not None] * 6 + [len(tactiles) > 0] * 6 + [True, False, False]
+        grads = _grad_targets(ctx.sink, ctx.params, used)
         L.check(L.lib().m3l_embed_bwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image),
                                       L.ptr_array(tactiles), L.ptr_array(tens), L.ptr(ws), L.ptr(dtokens),
                                       L.ptr_array(grads), _stream()), "m3l_embed_bwd")
-        return (None,) * 8 + tuple(grads)
+        _done(ctx.sink)
+        return (None,) * 9 + _returned(ctx.sink, grads)
 
 
 class TransformerFn(torch.autograd.Function):
@@ -112,7 +139,7 @@ class TransformerFn(torch.autograd.Function):
     compute-type copy, torch-side consumers the f32 one)."""
 
     @staticmethod
-    def forward(ctx, cfg, x, *tensors):
+    def forward(ctx, sink, cfg, x, *tensors):
         _require_cuda(x, "transformer input")
         B, n, D = x.shape
         assert D == cfg.dim, (D, cfg.dim)
@@ -124,6 +151,7 @@ class TransformerFn(torch.autograd.Function):
         L.check(L.lib().m3l_transformer_fwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws),
                                             L.ptr(y_t), L.ptr(y32), _stream()), "m3l_transformer_fwd")
         ctx.saved = (cfg, x, tens, ws)
+        ctx.params, ctx.sink = tensors, sink
         if y_t is None:
             y_t = y32.clone()     # f32 compute: two distinct autograd outputs over the same values
         return y_t, y32
@@ -139,16 +167,17 @@ class TransformerFn(torch.autograd.Function):
             code = DT_BF16 if dy.dtype == torch.bfloat16 else DT_F32
         else:
             dy, code = _f32c(dy32), DT_F32
-        grads = [torch.zeros_like(t) if t is not None else None for t in tens]
+        grads = _grad_targets(ctx.sink, ctx.params)
         dx = torch.empty_like(x)
         L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
                                             L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
-        return (None, dx) + tuple(grads)
+        _done(ctx.sink)
+        return (None, None, dx) + _returned(ctx.sink, grads)
 
 
 class UnshuffleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geom, D, dd, dt, unmasked, masked, enc_t, enc32, *tensors):
+    def forward(ctx, sink, geom, D, dd, dt, unmasked, masked, enc_t, enc32, *tensors):
         B, nvis = unmasked.shape
         nmask = masked.shape[1]
         dev = enc32.device
@@ -161,6 +190,7 @@ class UnshuffleFn(torch.autograd.Function):
                                           L.ptr(enc32), L.ptr(enc_t), L.ptr_array(tens), L.ptr(ws), L.ptr(dec_in),
                                           _stream()), "m3l_unshuffle_fwd")
         ctx.saved = (geom, D, dd, dt, unmasked, masked, enc_t, tens, ws)
+        ctx.params, ctx.sink = tensors, sink
         return dec_in
 
     @staticmethod
@@ -172,19 +202,20 @@ class UnshuffleFn(torch.autograd.Function):
         d_dec_in = _f32c(d_dec_in)
         proj = tens[0] is not None
         d_enc = torch.empty(B, nvis, D, dtype=(tdtype(dt) if proj else torch.float32), device=dev)
-        grads = [torch.zeros_like(t) if (t is not None and i < 4) else None for i, t in enumerate(tens)]
+        grads = _grad_targets(ctx.sink, ctx.params, [True, True, True, True, False, False])
         code = C.c_int(0)
         L.check(L.lib().m3l_unshuffle_bwd(C.byref(geom), D, dd, dt, B, nvis, nmask, L.ptr(unmasked), L.ptr(masked),
                                           L.ptr(enc_t), L.ptr_array(tens), L.ptr(ws), L.ptr(d_dec_in), L.ptr(d_enc),
                                           C.byref(code), L.ptr_array(grads), _stream()), "m3l_unshuffle_bwd")
+        _done(ctx.sink)
         if proj:      # gradient flows through the compute-type encoder output
-            return (None,) * 6 + (d_enc, None) + tuple(grads)
-        return (None,) * 6 + (None, d_enc) + tuple(grads)
+            return (None,) * 7 + (d_enc, None) + _returned(ctx.sink, grads)
+        return (None,) * 7 + (None, d_enc) + _returned(ctx.sink, grads)
 
 
 class HeadsLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geom, dd, dt, masked, nm_img, image, tactiles, dump, dec_t, *tensors):
+    def forward(ctx, sink, geom, dd, dt, masked, nm_img, image, tactiles, dump, dec_t, *tensors):
         B, N, _ = dec_t.shape
         nmask = masked.shape[1]
         dev = dec_t.device
@@ -208,6 +239,7 @@ class HeadsLossFn(torch.autograd.Function):
                 "m3l_heads_loss_fwd")
         ctx.saved = (geom, dd, dt, masked, nm_img, tens, ws, (B, N), dec_t.dtype)
         ctx.used = [image is not None] * 2 + [len(tactiles) > 0] * 2
+        ctx.params, ctx.sink = tensors, sink
         return loss
 
     @staticmethod
@@ -216,11 +248,12 @@ class HeadsLossFn(torch.autograd.Function):
         nmask = masked.shape[1]
         dloss = _f32c(dloss)
         d_dec = torch.empty(B, N, dd, dtype=ddtype, device=dloss.device)
-        grads = [torch.zeros_like(t) if (t is not None and ctx.used[i]) else None for i, t in enumerate(tens)]
+        grads = _grad_targets(ctx.sink, ctx.params, ctx.used)
         L.check(L.lib().m3l_heads_loss_bwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr_array(tens),
                                            L.ptr(ws), L.ptr(dloss), L.ptr(d_dec), L.ptr_array(grads), _stream()),
                 "m3l_heads_loss_bwd")
-        return (None,) * 8 + (d_dec,) + tuple(grads)
+        _done(ctx.sink)
+        return (None,) * 9 + (d_dec,) + _returned(ctx.sink, grads)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -74,6 +74,7 @@ class Transformer(nn.Module):
         self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
         self.project_out = not (heads == 1 and dim_head == dim)
         self.compute_dtype = "fp32"
+        self._sink = None            # (GradSync, bucket) when gradients go straight into a flat buffer (m3l_amd.parallel)
         self.norm = nn.LayerNorm(dim)
         self.layers = nn.ModuleList([])
         for _ in range(depth):
@@ -94,7 +95,7 @@ class Transformer(nn.Module):
 
     def run(self, x):
         """-> (y in compute dtype, y in f32); both carry gradient."""
-        return Fn.TransformerFn.apply(self._cfg(), x, *self._tensors())
+        return Fn.TransformerFn.apply(self._sink, self._cfg(), x, *self._tensors())
 
     def forward(self, x):
         return self.run(x)[1]
@@ -201,6 +202,7 @@ class VTMAE(nn.Module):
         self.encoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), encoder_dim)
         self.decoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), decoder_dim)
         self.set_compute_dtype(compute_dtype)
+        self._sinks = {}            # bucket name -> (GradSync, bucket id), filled by m3l_amd.parallel.GradSync
         self.last_mask = None       # (masked_indices, unmasked_indices) of the latest forward, int64 (B, *)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -239,7 +241,8 @@ class VTMAE(nn.Module):
 
     def _tokens(self, geom, image, tactiles, idx, cnt_img, L_tok):
         dt = Fn.dtype_code(self.compute_dtype)
-        return Fn.EmbedFn.apply(geom, self.encoder_dim, dt, idx, cnt_img, L_tok, image, tactiles, *self._embed_tensors())
+        return Fn.EmbedFn.apply(self._sinks.get("embed"), geom, self.encoder_dim, dt, idx, cnt_img, L_tok, image, tactiles,
+                                *self._embed_tensors())
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, x, use_vision=True, use_tactile=True, mask_noise=None, dump=None):
@@ -258,11 +261,11 @@ class VTMAE(nn.Module):
 
         tokens = self._tokens(geom, image, tactiles, unmasked, nvis_img, c["num_unmasked"])
         enc_t, enc32 = self.encoder.transformer.run(tokens)
-        dec_in = Fn.UnshuffleFn.apply(geom, self.encoder_dim, self.decoder_dim, dt, unmasked, masked, enc_t, enc32,
-                                      *self._glue_tensors())
+        dec_in = Fn.UnshuffleFn.apply(self._sinks.get("glue"), geom, self.encoder_dim, self.decoder_dim, dt, unmasked, masked,
+                                      enc_t, enc32, *self._glue_tensors())
         dec_t, _ = self.decoder.run(dec_in)
-        loss = Fn.HeadsLossFn.apply(geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles, dump, dec_t,
-                                    *self._head_tensors())
+        loss = Fn.HeadsLossFn.apply(self._sinks.get("heads"), geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles,
+                                    dump, dec_t, *self._head_tensors())
         if dump is not None:
             dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens.detach(), encoder_out=enc32.detach(),
                         decoder_in=dec_in.detach(), decoder_out=dec_t.detach())

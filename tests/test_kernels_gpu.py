@@ -141,7 +141,7 @@ def test_attention_softmax_spike(dev):
     torch.testing.assert_close(lse, ref_lse, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("D", [48, 64, 192, 384, 592, 768])
+@pytest.mark.parametrize("D", [48, 64, 192, 384, 592, 768, 1024])
 def test_layernorm_fwd_bwd(dev, D):
     torch.manual_seed(D)
     M = 1031

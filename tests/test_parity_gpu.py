@@ -203,3 +203,29 @@ def test_cfg2_full_size_properties():
     loss3 = mae({k: v[perm] for k, v in x.items()}, mask_noise=[n[perm] for n in noises])
     assert abs(float(loss3) - float(loss.detach())) <= 1e-3 * abs(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in mae.parameters() if p.grad is not None)
+
+
+def test_direct_grad_mode_matches_autograd_mode():
+    """GradSync makes the kernels write parameter gradients straight into one flat buffer (no autograd accumulate):
+    the values must be bit-identical to the gradients autograd receives in the default mode."""
+    from m3l_amd.parallel import GradSync
+    torch.manual_seed(3)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=128, depth=2, heads=2, mlp_dim=256)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, compute_dtype="bf16").to(DEV)
+    B = 5
+    x = {"image": torch.rand(B, 3, 32, 32, device=DEV), "tactile1": torch.rand(B, 3, 16, 16, device=DEV),
+         "tactile2": torch.rand(B, 3, 16, 16, device=DEV)}
+    noises = [torch.rand(B, 16, device=DEV) for _ in range(3)]
+    mae(x, mask_noise=noises).backward()
+    ref = {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}
+    mae.zero_grad(set_to_none=True)
+    sync = GradSync(mae)
+    sync.flat.fill_(float("nan"))          # every slot must be overwritten by its producer
+    mae(x, mask_noise=noises).backward()
+    sync.finish()
+    assert torch.isfinite(sync.flat).all()
+    for n, p in mae.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), n
+        else:
+            assert p.grad is None, n

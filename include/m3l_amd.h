@@ -110,11 +110,12 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream);
 
-/* ---- in-library HIP-event timing of kernel classes (bench.py roofline).  filter: substring of "kind[AxBxC]" or NULL = all. */
-void m3l_prof_begin(const char* filter);
+/* ---- in-library HIP-event timing of kernel classes (bench.py roofline).  filter: substring of "kind[AxBxC]" or NULL = all;
+ * stride: bracket every stride-th matching launch (sampling keeps the perturbation of the timed region small). */
+void m3l_prof_begin(const char* filter, int stride);
 void m3l_prof_end(void);
 int m3l_prof_count(void);
-int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* work_total);
+int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* flops_total, double* bytes_total);
 
 /* ---- raw kernels, exported for the per-kernel parity tests */
 int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,

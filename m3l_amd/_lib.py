@@ -48,10 +48,11 @@ _SIGS = {
     "m3l_gather_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "m3l_scatter_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "m3l_vt_load": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "m3l_prof_begin": (None, [C.c_char_p]),
+    "m3l_prof_begin": (None, [C.c_char_p, c_i]),
     "m3l_prof_end": (None, []),
     "m3l_prof_count": (c_i, []),
-    "m3l_prof_get": (c_i, [c_i, C.c_char_p, c_sz, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "m3l_prof_get": (c_i, [c_i, C.c_char_p, c_sz, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double)]),
     "m3l_op_gemm_nt": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "m3l_op_gemm_tn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "m3l_op_gemm_tn": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p, c_i, c_p]),

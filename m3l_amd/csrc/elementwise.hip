@@ -654,8 +654,8 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
                float* dx_out, void* dx_t_out, int ct_dtype, float* part_ws, float* dgamma, float* dbeta, float* dbias,
                int accumulate, hipStream_t st) {
     M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "ln_bwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
-    int G = cdiv(M, 2 * WPB);                    // >= 2 rows per wave; 8 workgroups per CU keep the HBM pipe full
-    if (G > 2048) G = 2048;
+    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 4 workgroups per CU
+    if (G > 1024) G = 1024;
     if (G < 1) G = 1;
     {
         ProfScope prof("ln_bwd", M, D, dy_dtype,

@@ -175,7 +175,14 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int wr = (BN == 128) ? (wave >> 1) : wave, wc = (BN == 128) ? (wave & 1) : 0;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
+    // XCD-aware tile order (guide T1): workgroup ids are dealt round-robin over the 8 XCDs, so ids that differ by a
+    // multiple of 8 share an L2.  All column tiles of one 128-row block get ids b, b+8, b+16, ... -> the A rows they
+    // share are fetched from HBM once per XCD-L2 instead of once per column tile.  Placement only affects speed.
+    const int gx = (N + BN - 1) / BN, gy = (M + 127) / 128;
+    const int bid = blockIdx.x, rest = bid >> 3;
+    const int bx = rest % gx, by = (rest / gx) * 8 + (bid & 7);
+    if (by >= gy) return;
+    const int m0 = by * 128, n0 = bx * BN;
 
     // per-lane source pointers of this wave's DMA segments (1 KiB = 8 rows x 8 chunks each)
     const int srow = lane >> 3, spc = lane & 7;
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
         if (tid < BN && n0 + tid < N) {
             float s = 0.f;
             for (int r = 0; r < RSTEP; ++r) s += red[r * BN + tid];
-            epi.colsum_part[(long)blockIdx.y * N + n0 + tid] = s;
+            epi.colsum_part[(long)by * N + n0 + tid] = s;
         }
     }
 }
@@ -436,6 +443,129 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, i
             }
 }
 
+// gemm_tn, main path: both operands arrive by LDS-DMA with hardware bounds checking (buffer_load ... lds: rows past M read
+// as zero, so ragged M needs no tail code), land in unpadded row-major [m][128] tiles whose 16-byte chunk index is XOR-ed
+// with a row-dependent mask on the SOURCE side, and are consumed k-strided: bf16 through ds_read_b64_tr_b16 (the 8 rows a
+// half-wave touches fall on 8 distinct 32-byte slots -> conflict-free), f32 through scalar reads.
+template <typename T> struct TnSwz;
+template <> struct TnSwz<bf16> {
+    static constexpr int ROWB = 256, CPR = 16, RPI = 4, BMT = 64;
+    static __device__ __forceinline__ int swz(int row) { return 2 * (row & 7); }
+};
+template <> struct TnSwz<float> {
+    static constexpr int ROWB = 512, CPR = 32, RPI = 2, BMT = 32;
+    static __device__ __forceinline__ int swz(int row) { return 4 * ((row >> 2) & 1); }
+};
+__device__ __forceinline__ Frag<bf16> load_ks_swz(const char* tile, int k0, int c0, int lane, bf16) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = k0 + 4 * g + q;
+    const int chunk = (c0 >> 3) + (p >> 1);
+    const int x = ((chunk ^ (2 * (r0 & 7))) << 4) + (p & 1) * 8;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + r0 * 256 + x));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + (r0 + 16) * 256 + x));
+    Frag<bf16> f;
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+    return f;
+}
+__device__ __forceinline__ Frag<float> load_ks_swz(const char* tile, int k0, int c0, int lane, float) {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = c0 + i, chunk = col >> 2, off = (col & 3) * 4;
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = k0 + 4 * g + (j & 3) + 16 * (j >> 2);
+        f.v[j] = *reinterpret_cast<const float*>(tile + r * 512 + ((chunk ^ (4 * ((r >> 2) & 1))) << 4) + off);
+    }
+    return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ Y, int ldy, const T* __restrict__ X, int ldx,
+                                                             int M, int N, int K, int m_per_split, int nsplit,
+                                                             float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using S = TnSwz<T>;
+    constexpr int ES = (int)sizeof(T), EPC = Chunk<T>::N;
+    constexpr int TILE_B = S::BMT * S::ROWB;          // 16 KiB per operand tile
+    constexpr int STAGE = 2 * TILE_B;
+    constexpr int MS = S::BMT / 32;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
+    // XCD-aware order: the (n, k) tiles of one m-split read the same rows of Y and X -> give them ids that differ by
+    // multiples of 8 (same XCD L2).
+    const int gn = (N + 127) / 128, gk = (K + 127) / 128, tiles = gn * gk;
+    const int bid = blockIdx.x, rest = bid >> 3;
+    const int tile = rest % tiles, sp = (rest / tiles) * 8 + (bid & 7);
+    if (sp >= nsplit) return;
+    const int n0 = (tile % gn) * 128, k0 = (tile / gn) * 128;
+    const int m_beg = sp * m_per_split;
+    const int m_end = min(M, m_beg + m_per_split);
+
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)min((long)M * ldy * ES, 2147483647L), 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((long)M * ldx * ES, 2147483647L), 0x00020000);
+    unsigned voy[4], vox[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * S::RPI + lane / S::CPR;
+        const int cc = (lane % S::CPR) ^ S::swz(row);
+        const int cy = min(n0 + cc * EPC, N - EPC), cx = min(k0 + cc * EPC, K - EPC);     // columns past N / K: any valid chunk
+        voy[i] = (unsigned)(((long)(m_beg + row) * ldy + cy) * ES);
+        vox[i] = (unsigned)(((long)(m_beg + row) * ldx + cx) * ES);
+    }
+    auto stage = [&](int st, int t) {
+        char* base = smem + st * STAGE;
+        const unsigned ady = (unsigned)((long)t * S::BMT * ldy * ES), adx = (unsigned)((long)t * S::BMT * ldx * ES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_vp)(base + (wave * 4 + i) * 1024), 16, voy[i] + ady, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vp)(base + TILE_B + (wave * 4 + i) * 1024), 16, vox[i] + adx, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (m_end - m_beg + S::BMT - 1) / S::BMT;     // m_per_split is a multiple of BMT: only the global tail is ragged
+    if (nt > 0) stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+        const char* Ys = smem + cur * STAGE;
+        const char* Xs = Ys + TILE_B;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            Frag<T> fa[4], fb[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                fa[x] = load_ks_swz(Ys, ms * 32, wr * 64 + x * 16, lane, T());
+                fb[x] = load_ks_swz(Xs, ms * 32, wc * 64 + x * 16, lane, T());
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+    float* P = partial + (long)sp * N * K;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 64 + a * 16 + 4 * g + r, k = k0 + wc * 64 + b * 16 + li;
+                if (n < N && k < K) P[(long)n * K + k] = acc[a][b][r];
+            }
+}
+
 __global__ void reduce_splits_kernel(const float* __restrict__ partial, int S, int N, int K, float* __restrict__ out, int ldo,
                                      int nvalid, int kvalid, int accumulate) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,6 +593,8 @@ int m3l_gemm_init() {
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_gemm_inited = 1;
@@ -479,17 +611,23 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
     M3L_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && epi->ldc % 8 == 0,
               "gemm_nt: K,N,lda,ldw,ldc must be multiples of 8 (got K=%d N=%d lda=%d ldw=%d ldc=%d)", K, N, lda, ldw, epi->ldc);
-    ProfScope prof("gemm_nt", M, N, K, 2.0 * M * N * K, st);
     const int bke = dtype == 1 ? 64 : 32;
+    const double es = dtype ? 2.0 : 4.0;
+    // algorithmic HBM bytes: A and W once, every epilogue operand / result once
+    const double bytes = (double)M * K * es + (double)N * K * es +
+                         (double)M * N * ((epi->res ? 4.0 : 0.0) + (epi->out_f32 ? 4.0 : 0.0) + (epi->out_t ? es : 0.0) +
+                                          (epi->out_pre ? es : 0.0) + (epi->gelu_u ? es : 0.0));
+    const char* kind = (K % bke != 0) ? "gemm_nt_generic" : ((N % 128 == 0 || N >= 1024) ? "gemm_nt_glds128" : "gemm_nt_glds64");
+    ProfScope prof(kind, M, N, K, 2.0 * M * N * K, st, bytes);
     if (K % bke == 0) {
         if (N % 128 == 0 || N >= 1024) {
-            dim3 grid(cdiv(N, 128), cdiv(M, 128));
+            dim3 grid(8 * cdiv(N, 128) * cdiv(cdiv(M, 128), 8));
             if (dtype == 1)
                 gemm_nt_glds_kernel<bf16, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
                 gemm_nt_glds_kernel<float, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
         } else {
-            dim3 grid(cdiv(N, 64), cdiv(M, 128));
+            dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 128), 8));
             if (dtype == 1)
                 gemm_nt_glds_kernel<bf16, 64><<<grid, 256, glds_lds_bytes(64), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
@@ -511,7 +649,7 @@ int m3l_gemm_nt_colsum_rows(int M) { return cdiv(M, 128); }
 
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
     const int tiles = cdiv(N, 128) * cdiv(K, 128);
-    int S = cdiv(768, tiles);                 // ~3 workgroups per CU over 256 CUs
+    int S = cdiv(384, tiles);                 // ~1.5 workgroups per CU over 256 CUs
     const int max_s = cdiv(M, 256);           // at least 256 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
@@ -533,8 +671,17 @@ int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M
     S = cdiv(M, mps);
     dim3 grid(cdiv(N, 128), cdiv(K, 128), S);
     {
-    ProfScope prof("gemm_tn", M, N, K, 2.0 * M * N * K, st);
-    if (dtype == 1)
+    ProfScope prof("gemm_tn", M, N, K, 2.0 * M * N * K, st, (double)M * (N + K) * (dtype ? 2.0 : 4.0) + (double)S * N * K * 4.0);
+    const long maxb = 2147483647L;
+    const bool dma_ok = (long)M * ldy * (dtype ? 2 : 4) < maxb && (long)M * ldx * (dtype ? 2 : 4) < maxb;
+    if (dma_ok) {
+        dim3 g1(8 * cdiv(N, 128) * cdiv(K, 128) * cdiv(S, 8), S);       // y only carries S (blockIdx.y unused: launched 1-D in x)
+        g1.y = 1;
+        if (dtype == 1)
+            gemm_tn_glds_kernel<bf16><<<g1, 256, 65536, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, S, partial_ws);
+        else
+            gemm_tn_glds_kernel<float><<<g1, 256, 65536, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, S, partial_ws);
+    } else if (dtype == 1)
         gemm_tn_kernel<bf16><<<grid, 256, TN_LDS_BYTES, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, partial_ws);
     else
         gemm_tn_kernel<float><<<grid, 256, TN_LDS_BYTES, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, partial_ws);

@@ -15,7 +15,8 @@
 struct ProfScope {
     int idx;
     hipStream_t stream;
-    ProfScope(const char* kind, long a, long b, long c, double work, hipStream_t st);
+    // work = algorithmic FLOPs of the launch, bytes = algorithmic HBM bytes (each operand / result once)
+    ProfScope(const char* kind, long a, long b, long c, double work, hipStream_t st, double bytes = 0.0);
     ~ProfScope();
 };
 

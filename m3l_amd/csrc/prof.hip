@@ -14,8 +14,10 @@
 
 namespace {
 struct Rec { int cls; hipEvent_t a, b; };
-struct Cls { std::string name; double ms = 0, work = 0; long launches = 0; double work_per_launch = 0; };
+struct Cls { std::string name; double ms = 0, work = 0, bytes = 0; long launches = 0; double work_per_launch = 0, bytes_per_launch = 0; };
 bool g_on = false;
+int g_stride = 1;
+long g_seen = 0;
 std::string g_filter;
 std::vector<Rec> g_recs;
 std::vector<Cls> g_cls;
@@ -34,11 +36,12 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-ProfScope::ProfScope(const char* kind, long a, long b, long c, double work, hipStream_t st) : idx(-1), stream(st) {
+ProfScope::ProfScope(const char* kind, long a, long b, long c, double work, hipStream_t st, double bytes) : idx(-1), stream(st) {
     if (!g_on) return;
     char name[96];
     snprintf(name, sizeof(name), "%s[%ldx%ldx%ld]", kind, a, b, c);
     if (!g_filter.empty() && strstr(name, g_filter.c_str()) == nullptr) return;
+    if ((g_seen++ % g_stride) != 0) return;          // sample every g_stride-th matching launch
     auto it = g_index.find(name);
     int cls;
     if (it == g_index.end()) {
@@ -47,6 +50,7 @@ ProfScope::ProfScope(const char* kind, long a, long b, long c, double work, hipS
         Cls cl;
         cl.name = name;
         cl.work_per_launch = work;
+        cl.bytes_per_launch = bytes;
         g_cls.push_back(cl);
     } else {
         cls = it->second;
@@ -64,7 +68,9 @@ ProfScope::~ProfScope() {
 }
 
 extern "C" {
-void m3l_prof_begin(const char* filter) {
+void m3l_prof_begin(const char* filter, int stride) {
+    g_stride = stride > 0 ? stride : 1;
+    g_seen = 0;
     g_recs.clear();
     g_cls.clear();
     g_index.clear();
@@ -80,6 +86,7 @@ void m3l_prof_end(void) {
             g_cls[r.cls].ms += ms;
             g_cls[r.cls].launches += 1;
             g_cls[r.cls].work += g_cls[r.cls].work_per_launch;
+            g_cls[r.cls].bytes += g_cls[r.cls].bytes_per_launch;
         }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
@@ -87,7 +94,7 @@ void m3l_prof_end(void) {
     g_recs.clear();
 }
 int m3l_prof_count(void) { return (int)g_cls.size(); }
-int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* work_total) {
+int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* work_total, double* bytes_total) {
     if (i < 0 || i >= (int)g_cls.size()) return 1;
     if (name && n) {
         strncpy(name, g_cls[i].name.c_str(), n - 1);
@@ -96,6 +103,7 @@ int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, 
     if (ms_total) *ms_total = g_cls[i].ms;
     if (launches) *launches = g_cls[i].launches;
     if (work_total) *work_total = g_cls[i].work;
+    if (bytes_total) *bytes_total = g_cls[i].bytes;
     return 0;
 }
 }

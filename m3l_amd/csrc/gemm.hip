@@ -8,6 +8,8 @@
 // Tile: 128 x 128 per 256-thread workgroup (2x2 waves of 64x64 = 4x4 MFMA tiles), register-staged double-buffered
 // LDS (global_load_dwordx4 issued before the MFMA block, ds_write after it: guide T14), epilogue staged through LDS
 // so that every global store is a 16-byte row segment.
+#include <string.h>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -482,9 +484,8 @@ __device__ __forceinline__ Frag<float> load_ks_swz(const char* tile, int k0, int
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ Y, int ldy, const T* __restrict__ X, int ldx,
-                                                             int M, int N, int K, int m_per_split, int nsplit,
-                                                             float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(TnGroup grp, int M, int m_per_split, int nsplit,
+                                                             float* __restrict__ partial_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = TnSwz<T>;
     constexpr int ES = (int)sizeof(T), EPC = Chunk<T>::N;
@@ -496,10 +497,20 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
     // XCD-aware order: the (n, k) tiles of one m-split read the same rows of Y and X -> give them ids that differ by
     // multiples of 8 (same XCD L2).
-    const int gn = (N + 127) / 128, gk = (K + 127) / 128, tiles = gn * gk;
     const int bid = blockIdx.x, rest = bid >> 3;
-    const int tile = rest % tiles, sp = (rest / tiles) * 8 + (bid & 7);
+    const int gtile = rest % grp.tiles_total, sp = (rest / grp.tiles_total) * 8 + (bid & 7);
     if (sp >= nsplit) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < grp.count && gtile >= grp.p[i].tile0) pi = i;
+    const TnProblem& pb = grp.p[pi];
+    const T* Y = reinterpret_cast<const T*>(pb.Y);
+    const T* X = reinterpret_cast<const T*>(pb.X);
+    const int ldy = pb.ldy, ldx = pb.ldx, N = pb.N, K = pb.K;
+    float* partial = partial_base + pb.part_off;
+    const int gn = (N + 127) / 128;
+    const int tile = gtile - pb.tile0;
     const int n0 = (tile % gn) * 128, k0 = (tile / gn) * 128;
     const int m_beg = sp * m_per_split;
     const int m_end = min(M, m_beg + m_per_split);
@@ -578,6 +589,25 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int S, i
     *o = accumulate ? (*o + s) : s;
 }
 
+__global__ void reduce_splits_grouped_kernel(TnGroup grp, const float* __restrict__ partial_base, int S, int accumulate) {
+    const TnProblem& pb = grp.p[blockIdx.y];
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long cnt = (long)pb.N * pb.K;
+    if (idx >= cnt) return;
+    const int n = (int)(idx / pb.K), k = (int)(idx % pb.K);
+    if (k >= pb.kvalid || n >= pb.nvalid) return;
+    const float* P = partial_base + pb.part_off + idx;
+    float s0 = 0.f, s1 = 0.f;
+    int i = 0;
+    for (; i + 1 < S; i += 2) {
+        s0 += P[(long)i * cnt];
+        s1 += P[(long)(i + 1) * cnt];
+    }
+    if (i < S) s0 += P[(long)i * cnt];
+    float* o = pb.out + (long)n * pb.ldo + k;
+    *o = accumulate ? (*o + (s0 + s1)) : (s0 + s1);
+}
+
 }  // namespace
 
 static constexpr int glds_lds_bytes(int bn) {
@@ -647,49 +677,84 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
 
 int m3l_gemm_nt_colsum_rows(int M) { return cdiv(M, 128); }
 
-size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
-    const int tiles = cdiv(N, 128) * cdiv(K, 128);
-    int S = cdiv(384, tiles);                 // ~1.5 workgroups per CU over 256 CUs
+static int tn_splits(int M, int tiles) {
+    int S = cdiv(512, tiles);                 // ~2 workgroups per CU over 256 CUs
     const int max_s = cdiv(M, 256);           // at least 256 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
+    return S;
+}
+
+size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
+    const int S = tn_splits(M, cdiv(N, 128) * cdiv(K, 128));
     if (splits_out) *splits_out = S;
     return (size_t)S * N * K * sizeof(float);
 }
 
-int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws,
-                size_t ws_bytes, float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st) {
+size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count) {
+    int tiles = 0;
+    size_t elems = 0;
+    for (int i = 0; i < count; ++i) {
+        tiles += cdiv(probs[i].N, 128) * cdiv(probs[i].K, 128);
+        elems += (size_t)probs[i].N * probs[i].K;
+    }
+    return (size_t)tn_splits(M, tiles > 0 ? tiles : 1) * elems * sizeof(float);
+}
+
+int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
+                        hipStream_t st) {
     if (m3l_gemm_init()) return 2;
     M3L_CHECK(dtype == 0 || dtype == 1, "gemm_tn: bad dtype %d", dtype);
-    M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem %d %d %d", M, N, K);
-    M3L_CHECK(K % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N,K,ldy,ldx must be multiples of 8");
-    int S;
-    const size_t need = m3l_gemm_tn_ws_bytes(M, N, K, &S);
-    M3L_CHECK(ws_bytes >= need, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need);
-    const int unit = (dtype == 1) ? 64 : 32;
-    int mps = cdiv(cdiv(M, S), unit) * unit;
+    M3L_CHECK(count >= 1 && count <= 4 && M > 0, "gemm_tn_grouped: count=%d M=%d", count, M);
+    const int es = dtype ? 2 : 4;
+    TnGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    int tiles = 0, maxnk = 0;
+    long off = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        TnProblem& p = probs[i];
+        M3L_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0 && p.N % 8 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0,
+                  "gemm_tn: N,K,ldy,ldx must be positive multiples of 8");
+        M3L_CHECK((long)M * p.ldy * es < 2147483647L && (long)M * p.ldx * es < 2147483647L, "gemm_tn: operand larger than 2 GiB");
+        p.tile0 = tiles;
+        tiles += cdiv(p.N, 128) * cdiv(p.K, 128);
+        if (p.N * p.K > maxnk) maxnk = p.N * p.K;
+        flops += 2.0 * M * p.N * p.K;
+        bytes += (double)M * (p.N + p.K) * es;
+    }
+    const int unit = dtype ? 64 : 32;
+    int S = tn_splits(M, tiles);
+    const int mps = cdiv(cdiv(M, S), unit) * unit;
     S = cdiv(M, mps);
-    dim3 grid(cdiv(N, 128), cdiv(K, 128), S);
+    for (int i = 0; i < count; ++i) {
+        probs[i].part_off = off;
+        off += (long)S * probs[i].N * probs[i].K;
+        grp.p[i] = probs[i];
+    }
+    grp.count = count;
+    grp.tiles_total = tiles;
+    M3L_CHECK(ws_bytes >= (size_t)off * sizeof(float), "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, (size_t)off * sizeof(float));
     {
-    ProfScope prof("gemm_tn", M, N, K, 2.0 * M * N * K, st, (double)M * (N + K) * (dtype ? 2.0 : 4.0) + (double)S * N * K * 4.0);
-    const long maxb = 2147483647L;
-    const bool dma_ok = (long)M * ldy * (dtype ? 2 : 4) < maxb && (long)M * ldx * (dtype ? 2 : 4) < maxb;
-    if (dma_ok) {
-        dim3 g1(8 * cdiv(N, 128) * cdiv(K, 128) * cdiv(S, 8), S);       // y only carries S (blockIdx.y unused: launched 1-D in x)
-        g1.y = 1;
+        ProfScope prof("gemm_tn", M, tiles, S, flops, st, bytes + (double)off * 4.0);
+        dim3 g1(8 * tiles * cdiv(S, 8));
         if (dtype == 1)
-            gemm_tn_glds_kernel<bf16><<<g1, 256, 65536, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, S, partial_ws);
+            gemm_tn_glds_kernel<bf16><<<g1, 256, 65536, st>>>(grp, M, mps, S, partial_ws);
         else
-            gemm_tn_glds_kernel<float><<<g1, 256, 65536, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, S, partial_ws);
-    } else if (dtype == 1)
-        gemm_tn_kernel<bf16><<<grid, 256, TN_LDS_BYTES, st>>>((const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, mps, partial_ws);
-    else
-        gemm_tn_kernel<float><<<grid, 256, TN_LDS_BYTES, st>>>((const float*)Y, ldy, (const float*)X, ldx, M, N, K, mps, partial_ws);
+            gemm_tn_glds_kernel<float><<<g1, 256, 65536, st>>>(grp, M, mps, S, partial_ws);
     }
     M3L_LAUNCH_CHECK();
-    ProfScope prof2("gemm_tn_reduce", S, N, K, (double)S * N * K * 4.0, st);
-    const long cnt = (long)N * K;
-    reduce_splits_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(partial_ws, S, N, K, out, ldo, nvalid, kvalid, accumulate);
+    ProfScope prof2("gemm_tn_reduce", S, tiles, count, 0.0, st, (double)off * 4.0);
+    reduce_splits_grouped_kernel<<<dim3(cdiv(maxnk, 256), count), 256, 0, st>>>(grp, partial_ws, S, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
+}
+
+int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws,
+                size_t ws_bytes, float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st) {
+    M3L_CHECK(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem %d %d %d", M, N, K);
+    TnProblem p;
+    memset(&p, 0, sizeof(p));
+    p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nvalid = nvalid; p.kvalid = kvalid;
+    return m3l_gemm_tn_grouped(dtype, &p, 1, M, partial_ws, ws_bytes, accumulate, st);
 }

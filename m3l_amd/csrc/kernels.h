@@ -57,6 +57,23 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);
 int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws, size_t ws_bytes,
                 float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st);
+// grouped weight-gradient GEMMs: up to 4 problems dW_i[N_i,K_i] = Y_i^T X_i that share M (one launch + one reduce)
+struct TnProblem {
+    const void* Y;
+    const void* X;
+    int ldy, ldx, N, K;
+    float* out;            // [nvalid, ldo] fp32
+    int ldo, nvalid, kvalid;
+    int tile0;             // filled by the launcher
+    long part_off;         // filled by the launcher (float offset of this problem's slabs)
+};
+struct TnGroup {
+    TnProblem p[4];
+    int count, tiles_total;
+};
+size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count);
+int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
+                        hipStream_t st);
 int m3l_gemm_init();
 int m3l_gemm_nt_colsum_rows(int M);   // number of partial rows written through GemmEpi::colsum_part
 

@@ -122,7 +122,7 @@ struct TfLayer {
 struct TfWs {
     std::vector<TfLayer> L;
     float* dx;
-    void *dx_t, *du, *dxn, *d_o, *dqkv;
+    void *dx_t, *dx1_t, *du, *dxn, *d_o, *dqkv;
     float* dsum;
     float* scratch;
     float* scratch2;      // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue
@@ -151,6 +151,7 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     }
     w.dx = a.take_n<float>(M * D);
     w.dx_t = a.take(M * D * e);
+    w.dx1_t = a.take(M * D * e);
     w.du = a.take(M * mlp * e);
     w.dxn = a.take(M * D * e);
     w.d_o = a.take(M * HD * e);
@@ -158,6 +159,13 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.dsum = a.take_n<float>((size_t)B * c->heads * n);
     std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
     w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
+    {
+        TnProblem pr[4];
+        memset(pr, 0, sizeof(pr));
+        pr[0].N = (int)D; pr[0].K = (int)mlp; pr[1].N = (int)mlp; pr[1].K = (int)D;
+        pr[2].N = (int)(3 * HD); pr[2].K = (int)D; pr[3].N = (int)D; pr[3].K = (int)HD;
+        w.scratch_b = std::max(w.scratch_b, m3l_gemm_tn_grouped_ws_bytes((int)M, pr, 4));
+    }
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch2 = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
     w.total = a.off + 256;
@@ -407,29 +415,36 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         e.out_t = w.du; e.gelu_u = L.u; e.colsum_part = w.scratch2;
         if (m3l_gemm_nt(dt, w.dx_t, D, L.w2T, D, M, mlp, D, &e, st)) return 1;                        // du = (dx W2) * gelu'(u)
         if (m3l_reduce_rows(w.scratch2, csrows, mlp, mlp, g[8], 0, st)) return 1;                     // fc1 bias grad
-        if (m3l_gemm_tn(dt, w.dx_t, D, L.h, mlp, M, D, mlp, w.scratch, w.scratch_b, g[9], mlp, D, mlp, 0, st)) return 1;
         e = epi0(D);
         e.out_t = w.dxn;
         if (m3l_gemm_nt(dt, w.du, mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                      // dxn2 = du W1
-        if (m3l_gemm_tn(dt, w.du, mlp, L.xn2, D, M, mlp, D, w.scratch, w.scratch_b, g[7], D, mlp, D, 0, st)) return 1;
-        // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
-        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx_t, dt, w.scratch, g[5], g[6],
+        // dx1 = dx + LN2-backward (in place), + compute-type copy (own buffer: dx_t is still a wgrad operand), + out-proj bias grad
+        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t, dt, w.scratch, g[5], g[6],
                        c->project_out ? g[4] : nullptr, 0, st))
             return 1;
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
-        const void* d_o = w.dx_t;
+        const void* d_o = w.dx1_t;
         if (c->project_out) {
             e = epi0(HD);
             e.out_t = w.d_o;
-            if (m3l_gemm_nt(dt, w.dx_t, D, L.woT, D, M, HD, D, &e, st)) return 1;                     // do = dx1 Wo
-            if (m3l_gemm_tn(dt, w.dx_t, D, L.o, HD, M, D, HD, w.scratch, w.scratch_b, g[3], HD, D, HD, 0, st)) return 1;
+            if (m3l_gemm_nt(dt, w.dx1_t, D, L.woT, D, M, HD, D, &e, st)) return 1;                    // do = dx1 Wo
             d_o = w.d_o;
         }
         if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv, B, n, c->heads, st)) return 1;
         e = epi0(D);
         e.out_t = w.dxn;
         if (m3l_gemm_nt(dt, w.dqkv, 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;         // dxn1 = dqkv Wqkv
-        if (m3l_gemm_tn(dt, w.dqkv, 3 * HD, L.xn1, D, M, 3 * HD, D, w.scratch, w.scratch_b, g[2], D, 3 * HD, D, 0, st)) return 1;
+        // ---- all weight gradients of the layer in ONE grouped TN launch + one reduce
+        {
+            TnProblem pr[4];
+            memset(pr, 0, sizeof(pr));
+            int np = 0;
+            pr[np++] = TnProblem{w.dx_t, L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0};                // dW2 = dx^T h
+            pr[np++] = TnProblem{w.du, L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};                  // dW1 = du^T xn2
+            pr[np++] = TnProblem{w.dqkv, L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0};      // dWqkv = dqkv^T xn1
+            if (c->project_out) pr[np++] = TnProblem{w.dx1_t, L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
+            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch, w.scratch_b, 0, st)) return 1;
+        }
         float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
         float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
         if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t : nullptr, dt, w.scratch, g[0], g[1],

@@ -2,6 +2,7 @@
 VTT / VTMAE representation path of Leonhard111/M3L (models/pretrain_models.py, models/VTT.py) and nothing else."""
 from ._lib import LIB_PATH, M3LError  # noqa: F401
 from .pretrain_models import VTMAE, VTT, Transformer  # noqa: F401
+from .dino_vtt import VTT as DinoVTT  # noqa: F401  (reference: models/VTT.py — a second class that is also called VTT)
 from .pretrain_utils import vt_load  # noqa: F401
 
-__all__ = ["VTT", "VTMAE", "Transformer", "vt_load", "M3LError", "LIB_PATH"]
+__all__ = ["VTT", "VTMAE", "Transformer", "DinoVTT", "vt_load", "M3LError", "LIB_PATH"]

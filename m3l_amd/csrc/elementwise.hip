@@ -17,7 +17,8 @@ __device__ __forceinline__ void store_val(bf16* p, float v) { *p = (bf16)v; }
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta    (nn.LayerNorm, biased variance).  One wave per row, one
 // 16-byte chunk (4 floats) per lane and pass: D = 192 keeps 48 lanes busy with a single global_load_dwordx4.
-constexpr int MAXC = 4;           // float4 chunks per lane: rows up to 1024 wide, D % 4 == 0
+// MAXC = float4 chunks per lane (template parameter): 1 for D <= 256, 2 for D <= 512, 4 for D <= 1024 (D % 4 == 0).
+// Specialising keeps a D = 192 row in 4 registers per array instead of 16 -> more waves per SIMD, more loads in flight.
 
 template <typename TO> __device__ __forceinline__ void store4(TO* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -33,6 +34,7 @@ __device__ __forceinline__ f32x4 load4(const bf16* p) {
 }
 
 // row statistics of x[row] held in registers v[] (chunk i of this lane = elements 4*(lane+64 i) .. +3)
+template <int MAXC>
 __device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x4 (&v)[MAXC], float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
@@ -54,7 +56,7 @@ __device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x
     rstd = rsqrtf(wave_sum(q) / D + eps);
 }
 
-template <typename TO>
+template <typename TO, int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, TO* __restrict__ y,
                                                        float* __restrict__ y32) {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= M) return;
     f32x4 v[MAXC];
     float mean, rstd;
-    row_stats(x + (long)row * D, D, lane, v, eps, mean, rstd);
+    row_stats<MAXC>(x + (long)row * D, D, lane, v, eps, mean, rstd);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int e = 4 * (lane + 64 * i);
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // LayerNorm backward.  dx_out = (dres ? dres : 0) + dLN/dx, optionally also stored in the compute type (dx_t_out: the
 // operand of the next dgrad / wgrad GEMM).  Per-block partials -> part[G][3*D]: dgamma | dbeta | column sums of dx_out
 // (= the bias gradient of the Linear whose output gradient dx_out is).
-template <typename TD, typename TC>
+template <typename TD, typename TC, int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, int M, int D,
                                                        const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
                                                        float* __restrict__ dx_out, TC* __restrict__ dx_t_out, float* __restrict__ part) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
     for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
         f32x4 v[MAXC], gdy[MAXC];
         float mean, rstd;
-        row_stats(x + (long)row * D, D, lane, v, eps, mean, rstd);
+        row_stats<MAXC>(x + (long)row * D, D, lane, v, eps, mean, rstd);
         const TD* dyr = dy + (long)row * D;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -634,12 +636,15 @@ static int part_grid(long rows) {
 
 int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, const float* beta, float eps, void* y, float* y32,
                hipStream_t st) {
-    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "ln_fwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
+    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "ln_fwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
     ProfScope prof("ln_fwd", M, D, out_dtype, (double)M * D * (4.0 + (y ? (out_dtype ? 2 : 4) : 0) + (y32 ? 4 : 0)), st);
-    if (out_dtype == 1)
-        ln_fwd_kernel<bf16><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (bf16*)y, y32);
-    else
-        ln_fwd_kernel<float><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (float*)y, y32);
+#define LN_FWD(TO, C) ln_fwd_kernel<TO, C><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (TO*)y, y32)
+    if (out_dtype == 1) {
+        if (D <= 256) LN_FWD(bf16, 1); else if (D <= 512) LN_FWD(bf16, 2); else LN_FWD(bf16, 4);
+    } else {
+        if (D <= 256) LN_FWD(float, 1); else if (D <= 512) LN_FWD(float, 2); else LN_FWD(float, 4);
+    }
+#undef LN_FWD
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -653,19 +658,20 @@ int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out,
 int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
                float* dx_out, void* dx_t_out, int ct_dtype, float* part_ws, float* dgamma, float* dbeta, float* dbias,
                int accumulate, hipStream_t st) {
-    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "ln_bwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
-    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 4 workgroups per CU
-    if (G > 1024) G = 1024;
+    M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "ln_bwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
+    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 8 workgroups per CU
+    if (G > 2048) G = 2048;
     if (G < 1) G = 1;
     {
         ProfScope prof("ln_bwd", M, D, dy_dtype,
                        (double)M * D * (4.0 + (dy_dtype ? 2 : 4) + (dres ? 4 : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
-        if (dy_dtype == 1)
-            ln_bwd_kernel<bf16, bf16><<<G, 256, 0, st>>>((const bf16*)dy, x, M, D, gamma, eps, dres, dx_out, (bf16*)dx_t_out, part_ws);
-        else if (ct_dtype == 1)
-            ln_bwd_kernel<float, bf16><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, (bf16*)dx_t_out, part_ws);
-        else
-            ln_bwd_kernel<float, float><<<G, 256, 0, st>>>((const float*)dy, x, M, D, gamma, eps, dres, dx_out, (float*)dx_t_out, part_ws);
+#define LN_BWD(TD, TC, C) ln_bwd_kernel<TD, TC, C><<<G, 256, 0, st>>>((const TD*)dy, x, M, D, gamma, eps, dres, dx_out, (TC*)dx_t_out, part_ws)
+#define LN_BWD_C(TD, TC) { if (D <= 256) LN_BWD(TD, TC, 1); else if (D <= 512) LN_BWD(TD, TC, 2); else LN_BWD(TD, TC, 4); }
+        if (dy_dtype == 1) LN_BWD_C(bf16, bf16)
+        else if (ct_dtype == 1) LN_BWD_C(float, bf16)
+        else LN_BWD_C(float, float)
+#undef LN_BWD_C
+#undef LN_BWD
     }
     M3L_LAUNCH_CHECK();
     ReduceSegs segs = {{dgamma, dbeta, dbias, nullptr}};

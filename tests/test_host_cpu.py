@@ -105,3 +105,20 @@ def test_no_cpu_fallback():
     x = {"image": torch.rand(2, 3, 32, 32), "tactile1": torch.rand(2, 3, 16, 16), "tactile2": torch.rand(2, 3, 16, 16)}
     with pytest.raises(m3l_amd.M3LError):
         mae(x)
+
+
+def test_dino_vtt_state_dict_and_pos_table(golden_dir):
+    z = np.load(os.path.join(golden_dir, "vtt_dino_small.npz"))
+    hw, p, D, depth, heads, mlp, B = [int(v) for v in z["meta"]]
+    enc = m3l_amd.DinoVTT(image_size=hw, tactile_size=hw, image_patch_size=p, tactile_patch_size=p, dim=D, depth=depth, heads=heads,
+                          mlp_dim=mlp, num_tactiles=2, num_register_tokens=0)
+    ref_keys = {k[len("param/"):] for k in z.files if k.startswith("param/")}
+    sd = enc.state_dict()
+    assert set(sd.keys()) == ref_keys, set(sd.keys()) ^ ref_keys
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == z["param/" + k].shape, k
+    np.testing.assert_allclose(enc.pos_embed(torch.device("cpu")).numpy(), z["pos_embed"], atol=1e-6)
+    # timm-style init: LayerNorm ones/zeros, Linear bias zeros, Linear weight ~ N(0, 0.02) (trunc at +-2 absolute)
+    assert float(enc.norm.weight.min()) == 1.0 and float(enc.transformer.layers[0][1].net[1].bias.abs().max()) == 0.0
+    assert abs(float(enc.image_to_patch_embedding[2].weight.std()) - 0.02) < 0.002
+    enc.load_state_dict({k: torch.tensor(z["param/" + k]) for k in ref_keys}, strict=True)

@@ -229,3 +229,67 @@ def test_direct_grad_mode_matches_autograd_mode():
             assert torch.equal(p.grad, ref[n]), n
         else:
             assert p.grad is None, n
+
+
+def test_dino_style_vtt_matches_reference_fixture(golden_dir):
+    """models/VTT.py forward / forward_features (with and without keep-index masks) vs the reference's own outputs."""
+    from m3l_amd import DinoVTT
+    z = np.load(os.path.join(golden_dir, "vtt_dino_small.npz"))
+    hw, p, D, depth, heads, mlp, B = [int(v) for v in z["meta"]]
+    enc = DinoVTT(image_size=hw, tactile_size=hw, image_patch_size=p, tactile_patch_size=p, dim=D, depth=depth, heads=heads,
+                  mlp_dim=mlp, num_tactiles=2, num_register_tokens=0)
+    enc.load_state_dict({k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    enc = enc.to(DEV).eval()
+    x = {k[len("input/"):]: torch.tensor(z[k]).to(DEV) for k in z.files if k.startswith("input/")}
+    masks = [torch.tensor(z["mask/0"]).to(DEV), torch.tensor(z["mask/1"]).to(DEV)]
+    with torch.no_grad():
+        full = enc.forward_features(x)
+        mk = enc(x, masks)
+    assert set(full.keys()) == {"x_norm_regtokens", "x_norm_patchtokens", "x_prenorm", "masks"}
+    np.testing.assert_allclose(full["x_prenorm"].cpu().numpy(), z["full/x_prenorm"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(full["x_norm_patchtokens"].cpu().numpy(), z["full/x_norm_patchtokens"], rtol=1e-3, atol=1e-4)
+    assert mk.shape == z["masked/x_norm_patchtokens"].shape
+    np.testing.assert_allclose(mk.cpu().numpy(), z["masked/x_norm_patchtokens"], rtol=1e-3, atol=1e-4)
+    # gradients flow to every embed / transformer / norm parameter and match the oracle
+    enc.train()
+    out = enc(x, masks)
+    out.square().mean().backward()
+    P = O.load_fixture_params(z, requires_grad=True)
+    r = O.vtt_dino_forward(P, image_patch=p, tactile_patch=p, depth=depth, heads=heads, x={k: v.cpu() for k, v in x.items()},
+                           masks=[m.cpu() for m in masks])
+    r["x_norm_patchtokens"].square().mean().backward()
+    for name, prm in enc.named_parameters():
+        ref = P[name].grad
+        if ref is None:
+            assert prm.grad is None, name
+            continue
+        err = float((prm.grad.cpu() - ref).abs().max()) / max(1e-7, float(ref.abs().max()))
+        assert err <= 5e-3, (name, err)
+
+
+def test_extractor_style_consumer_with_grad():
+    """MAEExtractor.forward (pretrain_models.py:819-841) = get_embeddings(eval=False) -> a 1-layer
+    Transformer -> mean over tokens, with gradients into the encoder — vs the oracle + torch on CPU."""
+    from m3l_amd import Transformer
+    torch.manual_seed(5)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128)
+    mae = VTMAE(encoder=enc, decoder_dim=64, decoder_depth=1, decoder_heads=2).to(DEV)
+    head = Transformer(64, 1, 4, 64, 128).to(DEV)
+    B = 3
+    x = {"image": torch.rand(B, 3, 32, 32, device=DEV), "tactile1": torch.rand(B, 3, 16, 16, device=DEV),
+         "tactile2": torch.rand(B, 3, 16, 16, device=DEV)}
+    feat = head(mae.get_embeddings(x, eval=False)).mean(dim=1)
+    assert feat.shape == (B, 64) and mae.training
+    feat.square().sum().backward()
+    cfg = O.OracleCfg(32, 16, 8, 4, 64, 2, 2, 128, 3, 2, 64, 1, 2, 0.75)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in mae.state_dict().items()}
+    PH = {"t." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in head.state_dict().items()}
+    emb = O.get_embeddings(P, cfg, {k: v.cpu() for k, v in x.items()})
+    ref = O.transformer(emb, PH, "t.", 1, 4, 64).mean(dim=1)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-3, atol=1e-4)
+    ref.square().sum().backward()
+    for name in ("encoder.transformer.layers.0.0.to_qkv.weight", "encoder.image_to_patch_embedding.2.weight", "encoder_modality_embedding.weight"):
+        g, gr = dict(mae.named_parameters())[name].grad.cpu(), P[name].grad
+        assert float((g - gr).abs().max()) <= 5e-3 * float(gr.abs().max()) + 1e-8, name
+    gh = head.layers[0][1].net[1].weight.grad.cpu()
+    assert float((gh - PH["t.layers.0.1.net.1.weight"].grad).abs().max()) <= 5e-3 * float(gh.abs().max()) + 1e-8

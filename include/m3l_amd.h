@@ -17,6 +17,7 @@
  *   m3l_transformer_*      vit_pytorch.vit.Transformer.forward (encoder :266, decoder :309, extractor :836)
  *   m3l_unshuffle_*        enc_to_dec + zeros/scatter/mask_token + decoder modality/sincos   :270-307
  *   m3l_heads_loss_*       masked-row gather + to_pixels/to_tactiles + F.mse_loss (x1 / x10)   :260-262,327-340
+ *   m3l_earlycnn_*         EarlyCNN.forward (early_conv_masking=True)                                   :37-56,180-191
  *   m3l_layernorm_*        nn.LayerNorm (models/VTT.py:354 final norm of the DINO-style encoder)
  *   m3l_vt_load            utils/pretrain_utils.py:7-57 (NHWC -> NCHW, per-sensor channel pick, [-1,1] -> [0,1])
  */
@@ -96,6 +97,27 @@ int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
 /* d_dec out: compute type (B, N, dd), zero on visible rows.  dloss: device f32 scalar (upstream gradient) or NULL for 1. */
 int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
                        const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream);
+
+/* ---- EarlyCNN stem (early_conv_masking=True, the reference's default flag; pretrain_models.py:37-56,180-191): three
+ * Conv2d+ReLU and a 1x1 Conv2d as im2col + MFMA GEMM.  srcs: nsrc NCHW f32 inputs of B samples each (the tactile sensors share
+ * one stem; they are processed as one batch of nsrc*B).  tensors / grads: {conv1.w, conv1.b, ..., conv4.w, conv4.b}.
+ * out: f32 (nsrc*B, h*w, dim) stem tokens (source-major). */
+typedef struct m3l_cnn_cfg {
+    int in_channels, height, width, dim;
+    int tactile;             /* 0: image stem (conv3 4/2/1), 1: tactile stem (conv3 3/1/1) */
+    int dtype;
+} m3l_cnn_cfg;
+size_t m3l_earlycnn_ws_bytes(const m3l_cnn_cfg* c, int B, int nsrc);
+int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* srcs, const void* const* tensors, void* ws, float* out,
+                     void* stream);
+int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const void* const* tensors, void* ws, const float* dout,
+                     float* const* grads, void* stream);
+/* stem tokens -> encoder tokens: + modality embedding + sincos position (pretrain_models.py:202-216); tensors {mod_emb, pos_img, pos_tac} */
+size_t m3l_tokens_assemble_ws_bytes(const m3l_geom* g, int D);
+int m3l_tokens_assemble_fwd(const m3l_geom* g, int D, int B, const float* img_tok, const float* tac_tok, const void* const* tensors,
+                            float* tokens, void* stream);
+int m3l_tokens_assemble_bwd(const m3l_geom* g, int D, int B, const float* dtokens, float* d_img, float* d_tac, void* ws, float* dmod,
+                            void* stream);
 
 /* ---- stand-alone ops (also used by the DINO-style VTT front end and by the unit tests) */
 size_t m3l_layernorm_ws_bytes(int D);

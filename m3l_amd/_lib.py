@@ -19,6 +19,10 @@ class Geom(C.Structure):
                                    "tactile_patch", "tactile_channels", "num_tactiles", "use_vision", "use_tactile")]
 
 
+class CnnCfg(C.Structure):
+    _fields_ = [(n, c_i) for n in ("in_channels", "height", "width", "dim", "tactile", "dtype")]
+
+
 class TfCfg(C.Structure):
     _fields_ = [(n, c_i) for n in ("dim", "depth", "heads", "mlp_dim", "project_out", "dtype")]
 
@@ -42,6 +46,12 @@ _SIGS = {
     "m3l_heads_loss_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                  c_p, c_p, c_p]),
     "m3l_heads_loss_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
+    "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_tokens_assemble_ws_bytes": (c_sz, [C.POINTER(Geom), c_i]),
+    "m3l_tokens_assemble_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_tokens_assemble_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_layernorm_ws_bytes": (c_sz, [c_i]),
     "m3l_layernorm_fwd": (c_i, [c_i, c_p, c_i, c_i, c_p, c_p, C.c_float, c_p, c_p, c_p]),
     "m3l_layernorm_bwd": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, C.c_float, c_p, c_p, c_p, c_p, c_p, c_p]),

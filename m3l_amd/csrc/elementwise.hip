@@ -250,6 +250,123 @@ __global__ void scale_by_dev_kernel(const T* __restrict__ x, long count, const f
     if (i < count) out[i] = from_f32<T>(to_f32(x[i]) * s[0]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// EarlyCNN stem (pretrain_models.py:37-56) as im2col + MFMA GEMM.  K order = (ci, kh, kw) = the Conv2d weight layout, so
+// the weight / weight-gradient matrices need no permutation.  Activations between the convolutions are NHWC
+// ([B*H*W, C], compute type) = exactly the [tokens, channels] matrix the next GEMM and the transformer consume.
+template <typename T>
+__global__ void im2col_kernel(ConvSrc cs, int Bsrc, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad,
+                              long total, T* __restrict__ col) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % Kpad);
+    const long r = idx / Kpad;
+    const int ow = (int)(r % OW), oh = (int)((r / OW) % OH);
+    const int b = (int)(r / ((long)OW * OH));
+    float v = 0.f;
+    if (k < Ci * KH * KH) {
+        const int kw = k % KH, kh = (k / KH) % KH, ci = k / (KH * KH);
+        const int ih = oh * S + kh - P, iw = ow * S + kw - P;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+            if (cs.nchw) {
+                const float* src = reinterpret_cast<const float*>(cs.src[b / Bsrc]);
+                v = src[(((long)(b % Bsrc) * Ci + ci) * H + ih) * W + iw];
+            } else {
+                v = to_f32(reinterpret_cast<const T*>(cs.src[0])[(((long)b * H + ih) * W + iw) * Ci + ci]);
+            }
+        }
+    }
+    col[idx] = from_f32<T>(v);
+}
+
+// adjoint of im2col in gather form (no atomics) + ReLU mask of the layer input: dX[b,ih,iw,ci] = act > 0 ? sum : 0
+template <typename T>
+__global__ void col2im_relu_kernel(const T* __restrict__ dcol, int Btot, int Ci, int H, int W, int KH, int S, int P, int OH, int OW,
+                                   int Kpad, const T* __restrict__ act, T* __restrict__ dX) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Btot * H * W * Ci) return;
+    const int ci = (int)(idx % Ci);
+    const long pix = idx / Ci;
+    const int iw = (int)(pix % W), ih = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    float s = 0.f;
+    if (to_f32(act[idx]) > 0.f) {
+        for (int kh = 0; kh < KH; ++kh) {
+            const int t = ih + P - kh;
+            if (t < 0 || t % S) continue;
+            const int oh = t / S;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < KH; ++kw) {
+                const int u = iw + P - kw;
+                if (u < 0 || u % S) continue;
+                const int ow = u / S;
+                if (ow >= OW) continue;
+                s += to_f32(dcol[(((long)b * OH + oh) * OW + ow) * Kpad + (ci * KH + kh) * KH + kw]);
+            }
+        }
+    }
+    dX[idx] = from_f32<T>(s);
+}
+
+// tokens[b, pos] = stem_token + modality[m(pos)] + sincos[pos]   (pretrain_models.py:202-216 on the EarlyCNN outputs;
+// tactile stem tokens arrive sensor-major: [k*B, n_tac, D])
+__global__ __launch_bounds__(256) void tokens_assemble_kernel(const float* __restrict__ img_tok, const float* __restrict__ tac_tok, int B,
+                                                                int D, int n_img, int n_tac, int k, const float* __restrict__ mod,
+                                                                const float* __restrict__ pos_img, const float* __restrict__ pos_tac,
+                                                                float* __restrict__ tokens) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int N = n_img + k * n_tac;
+    if (r >= (long)B * N) return;
+    const int b = (int)(r / N), pos = (int)(r % N);
+    const float *src, *prow;
+    int m;
+    if (pos < n_img) {
+        src = img_tok + ((long)b * n_img + pos) * D;
+        prow = pos_img + (long)pos * D;
+        m = 0;
+    } else {
+        const int local = pos - n_img, s = local / n_tac, p = local % n_tac;
+        src = tac_tok + (((long)s * B + b) * n_tac + p) * D;
+        prow = pos_tac + (long)local * D;
+        m = 1 + s;
+    }
+    float* out = tokens + r * D;
+    for (int e = lane; e < D; e += 64) out[e] = src[e] + mod[(long)m * D + e] + prow[e];
+}
+__global__ __launch_bounds__(256) void tokens_assemble_bwd_kernel(const float* __restrict__ dtok, int B, int D, int n_img, int n_tac, int k,
+                                                                    float* __restrict__ d_img, float* __restrict__ d_tac,
+                                                                    float* __restrict__ part) {
+    extern __shared__ float sm[];   // [WPB][(1 + k) * D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = n_img + k * n_tac, PL = (1 + k) * D;
+    for (int i = threadIdx.x; i < WPB * PL; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    float* my = sm + wave * PL;
+    for (long r = (long)blockIdx.x * WPB + wave; r < (long)B * N; r += (long)gridDim.x * WPB) {
+        const int b = (int)(r / N), pos = (int)(r % N);
+        float* dst;
+        int m;
+        if (pos < n_img) {
+            dst = d_img + ((long)b * n_img + pos) * D;
+            m = 0;
+        } else {
+            const int local = pos - n_img, s = local / n_tac, p = local % n_tac;
+            dst = d_tac + (((long)s * B + b) * n_tac + p) * D;
+            m = 1 + s;
+        }
+        const float* g = dtok + r * D;
+        for (int e = lane; e < D; e += 64) {
+            const float d = g[e];
+            dst[e] = d;
+            my[m * D + e] += d;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PL; i += 256)
+        part[(long)blockIdx.x * PL + i] = sm[i] + sm[PL + i] + sm[2 * PL + i] + sm[3 * PL + i];
+}
+
 // vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW (normalisation [0,1] is the identity);
 // tactile (B, 3*S*fs, h, w): sensor s takes channels {f*3S + 3s + c}, value (x + 1) / 2
 __global__ void vt_image_kernel(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out) {
@@ -722,6 +839,49 @@ int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t s
         cast_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>(x, count, (bf16*)out);
     else
         cast_kernel<float><<<cdiv(count, 256), 256, 0, st>>>(x, count, (float*)out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_im2col(int dtype, const ConvSrc* src, int Bsrc, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad, void* col,
+               hipStream_t st) {
+    const int Btot = src->nchw ? Bsrc * src->nsrc : Bsrc;
+    const long total = (long)Btot * OH * OW * Kpad;
+    if (dtype == 1)
+        im2col_kernel<bf16><<<cdiv(total, 256), 256, 0, st>>>(*src, Bsrc, Ci, H, W, KH, S, P, OH, OW, Kpad, total, (bf16*)col);
+    else
+        im2col_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(*src, Bsrc, Ci, H, W, KH, S, P, OH, OW, Kpad, total, (float*)col);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_col2im_relu(int dtype, const void* dcol, int Btot, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad,
+                    const void* act, void* dX, hipStream_t st) {
+    const long total = (long)Btot * H * W * Ci;
+    if (dtype == 1)
+        col2im_relu_kernel<bf16><<<cdiv(total, 256), 256, 0, st>>>((const bf16*)dcol, Btot, Ci, H, W, KH, S, P, OH, OW, Kpad, (const bf16*)act, (bf16*)dX);
+    else
+        col2im_relu_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)dcol, Btot, Ci, H, W, KH, S, P, OH, OW, Kpad, (const float*)act, (float*)dX);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int k_tokens_assemble(const float* img_tok, const float* tac_tok, int B, int D, int n_img, int n_tac, int k, const float* mod,
+                        const float* pos_img, const float* pos_tac, float* tokens, hipStream_t st) {
+    const long rows = (long)B * (n_img + k * n_tac);
+    tokens_assemble_kernel<<<cdiv(rows, WPB), 256, 0, st>>>(img_tok, tac_tok, B, D, n_img, n_tac > 0 ? n_tac : 1, k, mod, pos_img, pos_tac, tokens);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac, int k, float* d_img, float* d_tac, float* part_ws,
+                            float* dmod, int accumulate, hipStream_t st) {
+    const long rows = (long)B * (n_img + k * n_tac);
+    const int PL = (1 + k) * D;
+    const int G = part_grid(rows);
+    tokens_assemble_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, B, D, n_img, n_tac > 0 ? n_tac : 1, k, d_img, d_tac, part_ws);
+    M3L_LAUNCH_CHECK();
+    reduce_rows_kernel<<<cdiv(PL, 32), 256, 0, st>>>(part_ws, G, PL, PL, dmod, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }

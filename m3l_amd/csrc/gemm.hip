@@ -138,6 +138,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         if (epi.act == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        } else if (epi.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (epi.relu_ref) {
+            const T* rr = reinterpret_cast<const T*>(epi.relu_ref);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = to_f32(rr[o + j]) > 0.f ? v[j] : 0.f;
         }
         if (epi.res) {
 #pragma unroll
@@ -317,6 +325,14 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
             if (epi.act == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            } else if (epi.act == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (epi.relu_ref) {
+                const T* rr = reinterpret_cast<const T*>(epi.relu_ref);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = to_f32(rr[o + j]) > 0.f ? v[j] : 0.f;
             }
             if (epi.res) {
                 const f32x4 q0 = *reinterpret_cast<const f32x4*>(epi.res + o);

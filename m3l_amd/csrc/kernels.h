@@ -27,7 +27,8 @@ struct GemmEpi {
     void* out_t;           // compute-type [M, ldc] or null (post-activation)
     void* out_pre;         // compute-type [M, ldc] pre-activation copy or null
     const void* gelu_u;    // compute-type [M, ldc]: multiply by gelu'(u) (dgrad through GELU) or null
-    int act;               // 0 none, 1 GELU(erf)
+    int act;               // 0 none, 1 GELU(erf), 2 ReLU
+    const void* relu_ref;  // compute-type [M, ldc]: zero the result where relu_ref <= 0 (dgrad through ReLU) or null
     int ldc;
     float alpha;
     int n_bias;            // bias has n_bias valid entries (columns beyond read as 0); 0 -> N
@@ -95,6 +96,18 @@ int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t s
 int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
 int m3l_vt_load_launch(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                        int n_sensors, int frame_stack, float* const* tactile_out, hipStream_t st);
+struct ConvSrc {
+    const void* src[M3L_MAX_SENSORS];   // nchw: f32 [B, Ci, H, W] per source (sources concatenated on batch); else one NHWC compute-type [Btot*H*W, Ci]
+    int nsrc, nchw;
+};
+int m3l_im2col(int dtype, const ConvSrc* src, int Bsrc, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad, void* col,
+               hipStream_t st);
+int m3l_col2im_relu(int dtype, const void* dcol, int Btot, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad,
+                    const void* act, void* dX, hipStream_t st);
+int k_tokens_assemble(const float* img_tok, const float* tac_tok, int B, int D, int n_img, int n_tac, int k, const float* mod,
+                        const float* pos_img, const float* pos_tac, float* tokens, hipStream_t st);
+int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac, int k, float* d_img, float* d_tac, float* part_ws,
+                            float* dmod, int accumulate, hipStream_t st);
 int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
                   int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st);
 int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, const float* gamma,

@@ -656,6 +656,169 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// EarlyCNN stem
+namespace {
+struct ConvL { int Ci, Co, KH, S, P, H, W, OH, OW, K, Kpad; long M; };
+struct CnnWs {
+    ConvL L[4];
+    void *col[3], *act[3], *w[4], *wT[4];
+    void *dout_t, *dpreA, *dpreB, *dcol;
+    float* scratch;
+    size_t scratch_b, total;
+};
+CnnWs cnn_layout(const m3l_cnn_cfg* c, int Btot, void* ws) {
+    Arena a(ws);
+    CnnWs w;
+    const int D = c->dim;
+    const int co[4] = {D / 8, D / 4, D / 2, D};
+    int ci = c->in_channels, H = c->height, W = c->width;
+    for (int l = 0; l < 4; ++l) {
+        ConvL& L = w.L[l];
+        L.Ci = ci; L.Co = co[l]; L.H = H; L.W = W;
+        if (l == 3) { L.KH = 1; L.S = 1; L.P = 0; }
+        else if (l == 2 && c->tactile) { L.KH = 3; L.S = 1; L.P = 1; }
+        else { L.KH = 4; L.S = 2; L.P = 1; }
+        L.OH = (H + 2 * L.P - L.KH) / L.S + 1;
+        L.OW = (W + 2 * L.P - L.KH) / L.S + 1;
+        L.K = L.Ci * L.KH * L.KH;
+        L.Kpad = pad8(L.K);
+        L.M = (long)Btot * L.OH * L.OW;
+        ci = L.Co; H = L.OH; W = L.OW;
+    }
+    const size_t e = esz(c->dtype);
+    size_t max_pre = 0, max_col = 0;
+    for (int l = 0; l < 4; ++l) {
+        const ConvL& L = w.L[l];
+        w.w[l] = a.take((size_t)L.Co * L.Kpad * e);
+        w.wT[l] = a.take((size_t)L.Kpad * L.Co * e);
+        if (l < 3) {
+            w.col[l] = a.take((size_t)L.M * L.Kpad * e);
+            w.act[l] = a.take((size_t)L.M * L.Co * e);
+            max_col = std::max(max_col, (size_t)L.M * L.Kpad);
+        }
+        max_pre = std::max(max_pre, (size_t)L.M * L.Co);
+    }
+    w.dout_t = a.take((size_t)w.L[3].M * D * e);
+    w.dpreA = a.take(max_pre * e);
+    w.dpreB = a.take(max_pre * e);
+    w.dcol = a.take(max_col * e);
+    std::vector<std::pair<int, int>> shapes;
+    long Mmax = 1;
+    for (int l = 0; l < 4; ++l) { shapes.push_back({w.L[l].Co, w.L[l].Kpad}); Mmax = std::max(Mmax, w.L[l].M); }
+    w.scratch_b = 0;
+    for (int l = 0; l < 4; ++l) w.scratch_b = std::max(w.scratch_b, m3l_gemm_tn_ws_bytes((int)w.L[l].M, w.L[l].Co, w.L[l].Kpad, nullptr));
+    w.scratch_b = std::max(w.scratch_b, (size_t)M3L_MAX_PARTIAL_BLOCKS * D * sizeof(float));
+    w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.total = a.off + 256;
+    return w;
+}
+int check_cnn(const m3l_cnn_cfg* c, int B, int nsrc) {
+    M3L_CHECK(c->dtype == 0 || c->dtype == 1, "earlycnn: bad dtype");
+    M3L_CHECK(c->dim % 64 == 0, "earlycnn: dim=%d must be a multiple of 64", c->dim);
+    M3L_CHECK(B > 0 && nsrc >= 1 && nsrc <= M3L_MAX_SENSORS, "earlycnn: B=%d nsrc=%d", B, nsrc);
+    M3L_CHECK(c->height % 8 == 0 && c->width % 8 == 0 || (c->tactile && c->height % 4 == 0 && c->width % 4 == 0), "earlycnn: image size");
+    return 0;
+}
+}  // namespace
+
+size_t m3l_earlycnn_ws_bytes(const m3l_cnn_cfg* c, int B, int nsrc) {
+    if (check_cnn(c, B, nsrc)) return 0;
+    return cnn_layout(c, B * nsrc, nullptr).total;
+}
+
+int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* srcs, const void* const* tensors, void* ws, float* out,
+                     void* stream) {
+    if (check_cnn(c, B, nsrc)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int Btot = B * nsrc, dt = c->dtype;
+    CnnWs w = cnn_layout(c, Btot, ws);
+    for (int l = 0; l < 4; ++l) {
+        const ConvL& L = w.L[l];
+        M3L_HIP(hipMemsetAsync(w.w[l], 0, (size_t)L.Co * L.Kpad * esz(dt), st));
+        M3L_HIP(hipMemsetAsync(w.wT[l], 0, (size_t)L.Kpad * L.Co * esz(dt), st));
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.d[0] = WeightDesc{(const float*)tensors[2 * l], w.w[l], w.wT[l], L.Co, L.K, L.Kpad, L.Co};
+        pk.count = 1;
+        if (m3l_prep_weights(dt, &pk, st)) return 1;
+    }
+    ConvSrc cs;
+    memset(&cs, 0, sizeof(cs));
+    for (int i = 0; i < nsrc; ++i) cs.src[i] = srcs[i];
+    cs.nsrc = nsrc; cs.nchw = 1;
+    for (int l = 0; l < 3; ++l) {
+        const ConvL& L = w.L[l];
+        if (m3l_im2col(dt, &cs, l == 0 ? B : Btot, L.Ci, L.H, L.W, L.KH, L.S, L.P, L.OH, L.OW, L.Kpad, w.col[l], st)) return 1;
+        GemmEpi e = epi0(L.Co);
+        e.bias = (const float*)tensors[2 * l + 1];
+        e.act = 2;
+        e.out_t = w.act[l];
+        if (m3l_gemm_nt(dt, w.col[l], L.Kpad, w.w[l], L.Kpad, (int)L.M, L.Co, L.Kpad, &e, st)) return 1;
+        memset(&cs, 0, sizeof(cs));
+        cs.src[0] = w.act[l]; cs.nsrc = 1; cs.nchw = 0;
+    }
+    const ConvL& L3 = w.L[3];
+    GemmEpi e = epi0(L3.Co);
+    e.bias = (const float*)tensors[7];
+    e.out_f32 = out;
+    return m3l_gemm_nt(dt, w.act[2], L3.Kpad, w.w[3], L3.Kpad, (int)L3.M, L3.Co, L3.Kpad, &e, st);
+}
+
+int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const void* const* tensors, void* ws, const float* dout,
+                     float* const* grads, void* stream) {
+    if (check_cnn(c, B, nsrc)) return 1;
+    (void)tensors;
+    hipStream_t st = (hipStream_t)stream;
+    const int Btot = B * nsrc, dt = c->dtype, D = c->dim;
+    CnnWs w = cnn_layout(c, Btot, ws);
+    const ConvL& L3 = w.L[3];
+    // conv4 (1x1): dW4 = dout^T a2, db4 = colsum(dout), d(pre3) = (dout W4) masked by a2 > 0
+    if (m3l_cast_f32(dt, dout, L3.M * D, w.dout_t, st)) return 1;
+    if (m3l_gemm_tn(dt, w.dout_t, D, w.act[2], L3.Kpad, (int)L3.M, D, L3.Kpad, w.scratch, w.scratch_b, grads[6], L3.K, D, L3.K, 0, st)) return 1;
+    if (m3l_colsum(0, dout, (int)L3.M, D, D, w.scratch, grads[7], 0, st)) return 1;
+    void* dpre = w.dpreA;
+    void* dnext = w.dpreB;
+    {
+        GemmEpi e = epi0(L3.Kpad);
+        e.out_t = dpre; e.relu_ref = w.act[2];
+        if (m3l_gemm_nt(dt, w.dout_t, D, w.wT[3], D, (int)L3.M, L3.Kpad, D, &e, st)) return 1;   // [M, Co_2] (Kpad_3 == Co_2)
+    }
+    for (int l = 2; l >= 0; --l) {
+        const ConvL& L = w.L[l];
+        if (m3l_gemm_tn(dt, dpre, L.Co, w.col[l], L.Kpad, (int)L.M, L.Co, L.Kpad, w.scratch, w.scratch_b, grads[2 * l], L.K, L.Co, L.K, 0, st))
+            return 1;
+        if (m3l_colsum(dt, dpre, (int)L.M, L.Co, L.Co, w.scratch, grads[2 * l + 1], 0, st)) return 1;
+        if (l == 0) break;
+        GemmEpi e = epi0(L.Kpad);
+        e.out_t = w.dcol;
+        if (m3l_gemm_nt(dt, dpre, L.Co, w.wT[l], L.Co, (int)L.M, L.Kpad, L.Co, &e, st)) return 1;  // dcol = dpre W_l
+        if (m3l_col2im_relu(dt, w.dcol, Btot, L.Ci, L.H, L.W, L.KH, L.S, L.P, L.OH, L.OW, L.Kpad, w.act[l - 1], dnext, st)) return 1;
+        std::swap(dpre, dnext);
+    }
+    return 0;
+}
+
+size_t m3l_tokens_assemble_ws_bytes(const m3l_geom* g, int D) {
+    return (size_t)M3L_MAX_PARTIAL_BLOCKS * (1 + (g->num_tactiles > 0 ? g->num_tactiles : 0)) * D * sizeof(float) + 256;
+}
+int m3l_tokens_assemble_fwd(const m3l_geom* g, int D, int B, const float* img_tok, const float* tac_tok, const void* const* tensors,
+                            float* tokens, void* stream) {
+    if (check_geom(g)) return 1;
+    const Geo ge = geo_of(g);
+    return k_tokens_assemble(img_tok, tac_tok, B, D, ge.n_img, ge.n_tac, ge.k, (const float*)tensors[0], (const float*)tensors[1],
+                             (const float*)tensors[2], tokens, (hipStream_t)stream);
+}
+int m3l_tokens_assemble_bwd(const m3l_geom* g, int D, int B, const float* dtokens, float* d_img, float* d_tac, void* ws, float* dmod,
+                            void* stream) {
+    if (check_geom(g)) return 1;
+    const Geo ge = geo_of(g);
+    // slots of absent modalities get exact zeros from the reduction (their partial sums are zero)
+    float* part = (float*)ws;
+    // dmod has (1 + num_tactiles) rows in the model; this call fills rows [0, 1 + k) and the caller pre-zeroes the rest
+    return k_tokens_assemble_bwd(dtokens, B, D, ge.n_img, ge.n_tac, ge.k, d_img, d_tac, part, dmod, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // stand-alone ops
 size_t m3l_layernorm_ws_bytes(int D) { return (size_t)2048 * 3 * D * sizeof(float) + 256; }
 

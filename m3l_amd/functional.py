@@ -94,7 +94,7 @@ def _returned(sink, grads):
 
 
 def _done(sink):
-    if sink is not None:
+    if sink is not None and sink[1] is not None:      # bucket None: this Function only contributes part of a bucket
         sink[0].bucket_done(sink[1])
 
 
@@ -308,3 +308,70 @@ class GatherTokensFn(torch.autograd.Function):
         dx = torch.zeros(B, N, D, dtype=torch.float32, device=dy.device)
         L.check(L.lib().m3l_scatter_tokens(L.ptr(dy), B, N, D, L.ptr(idx), K, L.ptr(dx), _stream()), "m3l_scatter_tokens")
         return dx, None
+
+
+class EarlyCnnFn(torch.autograd.Function):
+    """EarlyCNN stem (pretrain_models.py:37-56) over a list of NCHW inputs that share the stem's weights (processed as one
+    batch): -> (len(srcs) * B, h * w, dim) f32 tokens, source-major.  tensors: conv1.w, conv1.b, ..., conv4.w, conv4.b."""
+
+    @staticmethod
+    def forward(ctx, sink, cfg, srcs, *tensors):
+        _require_cuda(srcs[0], "MAE input")
+        B, dev = srcs[0].shape[0], srcs[0].device
+        srcs = [_f32c(t) for t in srcs]
+        tens = [_f32c(t) for t in tensors]
+        nsrc = len(srcs)
+        ws = _ws(L.lib().m3l_earlycnn_ws_bytes(C.byref(cfg), B, nsrc), dev)
+        down = 4 if cfg.tactile else 8
+        hw = (cfg.height // down) * (cfg.width // down)
+        out = torch.empty(nsrc * B, hw, cfg.dim, dtype=torch.float32, device=dev)
+        L.check(L.lib().m3l_earlycnn_fwd(C.byref(cfg), B, nsrc, L.ptr_array(srcs), L.ptr_array(tens), L.ptr(ws), L.ptr(out),
+                                         _stream()), "m3l_earlycnn_fwd")
+        ctx.saved = (cfg, B, nsrc, srcs, tens, ws)
+        ctx.params, ctx.sink = tensors, sink
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg, B, nsrc, srcs, tens, ws = ctx.saved
+        dout = _f32c(dout)
+        grads = _grad_targets(ctx.sink, ctx.params)
+        L.check(L.lib().m3l_earlycnn_bwd(C.byref(cfg), B, nsrc, L.ptr_array(tens), L.ptr(ws), L.ptr(dout), L.ptr_array(grads),
+                                         _stream()), "m3l_earlycnn_bwd")
+        _done(ctx.sink)
+        return (None, None, None) + _returned(ctx.sink, grads)
+
+
+class TokensAssembleFn(torch.autograd.Function):
+    """stem tokens (+ modality embedding + sincos) -> (B, N, D) encoder tokens (pretrain_models.py:202-216)."""
+
+    @staticmethod
+    def forward(ctx, sink, geom, D, img_tok, tac_tok, mod, pos_img, pos_tac):
+        ref = img_tok if img_tok is not None else tac_tok
+        dev = ref.device
+        c = mask_counts(geom, 0.5)
+        N = c["num_masked"] + c["num_unmasked"]
+        B = img_tok.shape[0] if img_tok is not None else tac_tok.shape[0] // geom.num_tactiles
+        img_tok, tac_tok = _f32c(img_tok), _f32c(tac_tok)
+        tens = [_f32c(mod), _f32c(pos_img), _f32c(pos_tac)]
+        tokens = torch.empty(B, N, D, dtype=torch.float32, device=dev)
+        L.check(L.lib().m3l_tokens_assemble_fwd(C.byref(geom), D, B, L.ptr(img_tok), L.ptr(tac_tok), L.ptr_array(tens),
+                                                L.ptr(tokens), _stream()), "m3l_tokens_assemble_fwd")
+        ctx.saved = (geom, D, B, None if img_tok is None else img_tok.shape, None if tac_tok is None else tac_tok.shape)
+        ctx.params, ctx.sink = (mod,), sink
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtok):
+        geom, D, B, ishape, tshape = ctx.saved
+        dtok = _f32c(dtok)
+        dev = dtok.device
+        d_img = torch.empty(ishape, dtype=torch.float32, device=dev) if ishape is not None else None
+        d_tac = torch.empty(tshape, dtype=torch.float32, device=dev) if tshape is not None else None
+        (gmod,) = _grad_targets(ctx.sink, ctx.params)
+        gmod.zero_()                                  # rows of sensors absent from this call keep a zero gradient
+        ws = _ws(L.lib().m3l_tokens_assemble_ws_bytes(C.byref(geom), D), dev)
+        L.check(L.lib().m3l_tokens_assemble_bwd(C.byref(geom), D, B, L.ptr(dtok), L.ptr(d_img), L.ptr(d_tac), L.ptr(ws), L.ptr(gmod),
+                                                _stream()), "m3l_tokens_assemble_bwd")
+        _done(ctx.sink)
+        return (None, None, None, d_img, d_tac) + _returned(ctx.sink, [gmod]) + (None, None)

@@ -24,7 +24,7 @@ def _bucket_of(name: str) -> int:
         return 2
     if name.startswith("encoder.transformer"):
         return 3
-    return 4        # patch embed, encoder modality embedding
+    return 4        # patch embed / EarlyCNN stems, encoder modality embedding
 
 
 class GradSync:
@@ -61,6 +61,7 @@ class GradSync:
             count += 1
         self.buckets.append([start, off, count])
         self._works = []
+        self._reduced = set()
         self.params = [p for _, p in named]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
@@ -71,16 +72,22 @@ class GradSync:
 
     def zero_grad(self):
         self.flat.zero_()
+        self._reduced = set()
 
     def bucket_done(self, bucket_id: int):
         """Called from the backward of the module that owns `bucket_id` once its gradients are in the flat buffer."""
+        self._reduced.add(bucket_id)
         if self.world <= 1 or bucket_id not in self._bucket_ids:
             return
         s, e, _ = self.buckets[self._bucket_ids.index(bucket_id)]
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Make the compute stream wait for every outstanding all-reduce (call before optimizer.step())."""
+        """Reduce the buckets nobody reported (modules whose gradients come from several Functions), then make the compute
+        stream wait for every outstanding all-reduce (call before optimizer.step())."""
+        for b in self._bucket_ids:
+            if b not in self._reduced:
+                self.bucket_done(b)
         for w in self._works:
             w.wait()
         if self._works:

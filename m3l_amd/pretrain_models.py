@@ -101,6 +101,36 @@ class Transformer(nn.Module):
         return self.run(x)[1]
 
 
+class EarlyCNN(nn.Module):
+    """Parameter layout of the reference's conv stem (pretrain_models.py:37-56); the arithmetic runs as im2col + MFMA GEMM
+    in the HIP library (m3l_earlycnn_fwd/bwd)."""
+
+    def __init__(self, in_channels, encoder_dim, key='image'):
+        super().__init__()
+        self.key = key
+        self.in_channels, self.encoder_dim = in_channels, encoder_dim
+        self.conv1 = nn.Conv2d(in_channels, encoder_dim // 8, 4, stride=2, padding=1)
+        self.conv2 = nn.Conv2d(encoder_dim // 8, encoder_dim // 4, 4, stride=2, padding=1)
+        if key == 'image':
+            self.conv3 = nn.Conv2d(encoder_dim // 4, encoder_dim // 2, 4, stride=2, padding=1)
+        else:
+            self.conv3 = nn.Conv2d(encoder_dim // 4, encoder_dim // 2, 3, stride=1, padding=1)
+        self.conv4 = nn.Conv2d(encoder_dim // 2, encoder_dim, 1)
+
+    def _tensors(self):
+        return [self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias,
+                self.conv4.weight, self.conv4.bias]
+
+    def run(self, xs, compute_dtype="fp32", sink=None):
+        """xs: list of (B, C, H, W) inputs sharing this stem -> (len(xs) * B, h*w, D) tokens, input-major."""
+        H, W = xs[0].shape[-2:]
+        cfg = L.CnnCfg(self.in_channels, H, W, self.encoder_dim, int(self.key != 'image'), Fn.dtype_code(compute_dtype))
+        return Fn.EarlyCnnFn.apply(sink, cfg, list(xs), *self._tensors())
+
+    def forward(self, x):
+        return self.run([x])
+
+
 class VTT(nn.Module):
     """Encoder container of the reference (pretrain_models.py:717-786): two patch-embed Sequentials, learned
     pos_embedding (unused under sincos), Transformer.  Like the reference it has no forward."""
@@ -160,8 +190,6 @@ class VTMAE(nn.Module):
                  num_tactiles=2, early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=1, compute_dtype="fp32"):
         super().__init__()
         assert masking_ratio > 0 and masking_ratio < 1, 'masking ratio must be kept between 0 and 1'
-        if early_conv_masking:
-            raise NotImplementedError("early_conv_masking=True (EarlyCNN stem, pretrain_models.py:37-56) is not built yet (SURVEY 8f-2)")
         if not use_sincosmod_encodings:
             raise NotImplementedError("use_sincosmod_encodings=False (learned positions) is not built in the HIP path")
         self.masking_ratio = masking_ratio
@@ -172,6 +200,9 @@ class VTMAE(nn.Module):
         num_decoder_patches = num_patches - 1
         self.use_sincosmod_encodings = use_sincosmod_encodings
         self.early_conv_masking = early_conv_masking
+        if self.early_conv_masking:
+            self.early_conv_vision = EarlyCNN(self.encoder.image_channels, encoder_dim, key='image')
+            self.early_conv_tactile = EarlyCNN(self.encoder.tactile_channels, encoder_dim, key='tactile')
 
         self.image_to_patch = encoder.image_to_patch_embedding[0]
         self.image_patch_to_emb = nn.Sequential(*encoder.image_to_patch_embedding[1:])
@@ -239,8 +270,19 @@ class VTMAE(nn.Module):
         geom = Fn.make_geom(self.encoder, self.num_tactiles, use_vision, use_tactile)
         return image, tactiles, geom, ref
 
+    def _stem_tokens(self, geom, image, tactiles):
+        """early_conv_masking=True: EarlyCNN stems over the whole frames, then + modality + sincos -> (B, N, D)."""
+        part = (self._sinks["embed"][0], None) if "embed" in self._sinks else None     # three Functions share the embed bucket
+        img_tok = self.early_conv_vision.run([image], self.compute_dtype, part) if image is not None else None
+        tac_tok = self.early_conv_tactile.run(tactiles, self.compute_dtype, part) if tactiles else None
+        return Fn.TokensAssembleFn.apply(part, geom, self.encoder_dim, img_tok, tac_tok, self.encoder_modality_embedding.weight,
+                                         self.image_enc_pos_embedding[0], self.tactile_enc_pos_embedding[0])
+
     def _tokens(self, geom, image, tactiles, idx, cnt_img, L_tok):
         dt = Fn.dtype_code(self.compute_dtype)
+        if self.early_conv_masking:
+            tokens = self._stem_tokens(geom, image, tactiles)
+            return tokens if idx is None else Fn.GatherTokensFn.apply(tokens, idx)
         return Fn.EmbedFn.apply(self._sinks.get("embed"), geom, self.encoder_dim, dt, idx, cnt_img, L_tok, image, tactiles,
                                 *self._embed_tensors())
 
@@ -264,8 +306,15 @@ class VTMAE(nn.Module):
         dec_in = Fn.UnshuffleFn.apply(self._sinks.get("glue"), geom, self.encoder_dim, self.decoder_dim, dt, unmasked, masked,
                                       enc_t, enc32, *self._glue_tensors())
         dec_t, _ = self.decoder.run(dec_in)
-        loss = Fn.HeadsLossFn.apply(self._sinks.get("heads"), geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles,
-                                    dump, dec_t, *self._head_tensors())
+        if self.early_conv_masking:
+            # pretrain_models.py:311-322: predict ALL patches, loss over all of them (same kernel, identity index list)
+            N = c["num_masked"] + c["num_unmasked"]
+            rows = torch.arange(N, device=dev, dtype=torch.int64).expand(B, N).contiguous()
+            loss = Fn.HeadsLossFn.apply(self._sinks.get("heads"), geom, self.decoder_dim, dt, rows, c["n_img"], image, tactiles,
+                                        dump, dec_t, *self._head_tensors())
+        else:
+            loss = Fn.HeadsLossFn.apply(self._sinks.get("heads"), geom, self.decoder_dim, dt, masked, c["nm_img"], image, tactiles,
+                                        dump, dec_t, *self._head_tensors())
         if dump is not None:
             dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens.detach(), encoder_out=enc32.detach(),
                         decoder_in=dec_in.detach(), decoder_out=dec_t.detach())

@@ -16,6 +16,7 @@ What it restates (plain PyTorch on CPU, fp32 or fp64, autograd for the backward)
   un-shuffle         :279-307
   heads + loss       :327-340
   get_embeddings     :588-668
+  EarlyCNN stem      :37-56,180-191,311-322   (early_conv_masking=True, the reference's default flag)
   SinusoidalEmbed    /root/reference/tactile_ssl/model/layers/patch_embed.py:133-224 (+ create_ndgrid utils/__init__.py:39-69)
   apply_masks        /root/reference/tactile_ssl/utils/__init__.py:25-36
   DINO-style VTT     /root/reference/models/VTT.py:280-360,424-426
@@ -187,18 +188,35 @@ def _embed(patches, P, key):
     return F.layer_norm(h, (h.shape[-1],), P[key + ".3.weight"], P[key + ".3.bias"], 1e-5)
 
 
+def early_cnn(x, P, prefix: str, key: str):
+    """EarlyCNN.forward (pretrain_models.py:37-56): conv 4/2/1 + ReLU, conv 4/2/1 + ReLU, conv 4/2/1 (image) or 3/1/1 (tactile)
+    + ReLU, conv 1x1; flatten(2).transpose(1, 2) -> (B, h*w, D)."""
+    x = F.relu(F.conv2d(x, P[prefix + "conv1.weight"], P[prefix + "conv1.bias"], stride=2, padding=1))
+    x = F.relu(F.conv2d(x, P[prefix + "conv2.weight"], P[prefix + "conv2.bias"], stride=2, padding=1))
+    if key == "image":
+        x = F.relu(F.conv2d(x, P[prefix + "conv3.weight"], P[prefix + "conv3.bias"], stride=2, padding=1))
+    else:
+        x = F.relu(F.conv2d(x, P[prefix + "conv3.weight"], P[prefix + "conv3.bias"], stride=1, padding=1))
+    return F.conv2d(x, P[prefix + "conv4.weight"], P[prefix + "conv4.bias"]).flatten(2).transpose(1, 2)
+
+
 def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=True, use_tactile=True):
-    """patchify + embed + modality + sincos for ALL patches (pretrain_models.py:154-216)."""
+    """patchify + embed (or EarlyCNN stem when the parameters hold one) + modality + sincos for ALL patches
+    (pretrain_models.py:154-216)."""
     dt = P["mask_token"].dtype
+    early = "early_conv_vision.conv1.weight" in P
     toks, img_patches, tac_patches = [], None, None
     if use_vision:
         img_patches = patchify(x["image"].to(dt), cfg.image_patch)
-        t = _embed(img_patches, P, "encoder.image_to_patch_embedding")
+        t = early_cnn(x["image"].to(dt), P, "early_conv_vision.", "image") if early else _embed(img_patches, P, "encoder.image_to_patch_embedding")
         t = t + P["encoder_modality_embedding.weight"][0] + P["image_enc_pos_embedding"][0]
         toks.append(t)
     if cfg.num_tactiles > 0 and use_tactile:
         tac_patches = torch.cat([patchify(x[f"tactile{i + 1}"].to(dt), cfg.tactile_patch) for i in range(cfg.num_tactiles)], 1)
-        t = _embed(tac_patches, P, "encoder.tactile_to_patch_embedding")
+        if early:
+            t = torch.cat([early_cnn(x[f"tactile{i + 1}"].to(dt), P, "early_conv_tactile.", "tactile") for i in range(cfg.num_tactiles)], 1)
+        else:
+            t = _embed(tac_patches, P, "encoder.tactile_to_patch_embedding")
         mod = P["encoder_modality_embedding.weight"][1:1 + cfg.num_tactiles].repeat_interleave(cfg.n_tac, 0)
         t = t + mod + P["tactile_enc_pos_embedding"][0]
         toks.append(t)
@@ -236,6 +254,18 @@ def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch
     out["decoder_out"] = dec
     loss = torch.zeros((), dtype=tokens.dtype)
     mi_img, mi_tac = masked_t[:, :nm_img], masked_t[:, nm_img:]
+    if "early_conv_vision.conv1.weight" in P:
+        # early_conv_masking=True (pretrain_models.py:311-322): predict ALL patches, loss over all of them
+        if nt > 0:
+            pred_t = dec[:, n_img:] @ P["to_tactiles.weight"].t() + P["to_tactiles.bias"]
+            out["pred_tactile"], out["target_tactile"] = pred_t, tac_patches
+            loss = loss + 10 * F.mse_loss(pred_t, tac_patches)
+        if use_vision:
+            pred_i = dec[:, :n_img] @ P["to_pixels.weight"].t() + P["to_pixels.bias"]
+            out["pred_pixel"], out["target_pixel"] = pred_i, img_patches
+            loss = loss + F.mse_loss(pred_i, img_patches)
+        out["loss"] = loss
+        return out
     if nt > 0:
         pred_t = dec[br, mi_tac] @ P["to_tactiles.weight"].t() + P["to_tactiles.bias"]
         tgt_t = tac_patches[br, mi_tac - n_img]

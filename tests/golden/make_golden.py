@@ -103,13 +103,13 @@ def _noise(gen, B, n, tie_row=None):
 
 
 def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp, C, num_tactiles,
-             dec_dim, dec_depth, dec_heads, ratio, B, seed, with_embeddings=False):
+             dec_dim, dec_depth, dec_heads, ratio, B, seed, with_embeddings=False, early_conv=False):
     torch.manual_seed(seed)
     enc = ref.VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp_,
                   dim=dim, depth=depth, heads=heads, mlp_dim=mlp, image_channels=C, tactile_channels=C,
                   num_tactiles=num_tactiles)
     mae = ref.VTMAE(encoder=enc, decoder_dim=dec_dim, masking_ratio=ratio, decoder_depth=dec_depth,
-                    decoder_heads=dec_heads, num_tactiles=num_tactiles, early_conv_masking=False,
+                    decoder_heads=dec_heads, num_tactiles=num_tactiles, early_conv_masking=early_conv,
                     use_sincosmod_encodings=True)
     # make LN affine / biases non-trivial so that every parameter is exercised
     g = torch.Generator().manual_seed(seed + 1)
@@ -135,7 +135,12 @@ def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp
             cap[key + "_out"] = out.detach().clone()
         return f
 
-    hs = [mae.encoder.transformer.register_forward_hook(hook("encoder")),
+    if early_conv:
+        hs_extra = [mae.early_conv_vision.register_forward_hook(hook("early_conv_vision")),
+                    mae.early_conv_tactile.register_forward_hook(hook("early_conv_tactile"))]
+    else:
+        hs_extra = []
+    hs = hs_extra + [mae.encoder.transformer.register_forward_hook(hook("encoder")),
           mae.decoder.register_forward_hook(hook("decoder")),
           mae.to_pixels.register_forward_hook(hook("to_pixels")),
           mae.to_tactiles.register_forward_hook(hook("to_tactiles")),
@@ -165,6 +170,7 @@ def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp
                             dec_dim, dec_depth, dec_heads, B], dtype=np.int64)
     out["ratio"] = np.array(ratio, dtype=np.float64)
     out["unused_params"] = np.array([k for k, p in mae.named_parameters() if p.grad is None])
+    out["early_conv"] = np.array(int(early_conv))
 
     if with_embeddings:
         with torch.no_grad():
@@ -246,6 +252,9 @@ def main():
     # D: cfg-2 token geometry exactly (64x64/P8 + 2x 32x32/P4 -> 192 tokens, 48 visible), narrow model
     run_case(ref, "vt_cfg2_geom", image_hw=64, tactile_hw=32, ip=8, tp_=4, dim=64, depth=1, heads=1, mlp=64, C=3,
              num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=1, ratio=0.75, B=2, seed=14)
+    # E: the reference's DEFAULT flag early_conv_masking=True (EarlyCNN stem, loss over all patches), mask 0.95
+    run_case(ref, "vt_earlyconv", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=1, heads=2, mlp=128, C=3,
+             num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=15, with_embeddings=True, early_conv=True)
     run_vt_load(ref)
     run_vtt_dino()
 

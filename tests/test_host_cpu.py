@@ -56,10 +56,10 @@ def _build(z):
     enc = m3l_amd.VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp, dim=dim,
                       depth=depth, heads=heads, mlp_dim=mlp, image_channels=Cc, tactile_channels=Cc, num_tactiles=k)
     return m3l_amd.VTMAE(encoder=enc, decoder_dim=dd, masking_ratio=float(z["ratio"]), decoder_depth=ddepth,
-                         decoder_heads=dheads, num_tactiles=k)
+                         decoder_heads=dheads, num_tactiles=k, early_conv_masking=bool(int(z["early_conv"])))
 
 
-@pytest.mark.parametrize("name,seed", [("vt_small", 11), ("v_only_small", 12), ("vt_decdim", 13)])
+@pytest.mark.parametrize("name,seed", [("vt_small", 11), ("v_only_small", 12), ("vt_decdim", 13), ("vt_earlyconv", 15)])
 def test_state_dict_keys_shapes_and_init_match_reference(golden_dir, name, seed):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     torch.manual_seed(seed)

@@ -8,7 +8,7 @@ import torch
 
 from oracle import vtmae_oracle as O
 
-CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom"]
+CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv"]
 
 
 def _load(golden_dir, name):
@@ -45,8 +45,9 @@ def test_mask_indices_bit_exact(golden_dir, name):
     assert saw_tie, "fixtures are expected to contain crafted tied rows"
     masked, unmasked, nm_img, nm_tac = O.mask_indices([n.numpy() for n in noises], cfg.ratio, cfg.n_img, cfg.n_tac, cfg.num_tactiles)
     assert masked.dtype == np.int64 and unmasked.dtype == np.int64
-    # counts: reference shapes (decoder gathers)
-    assert masked.shape[1] == z["cap/to_pixels_in"].shape[1] + z["cap/to_tactiles_in"].shape[1]
+    # counts: reference shapes (decoder gathers; with early_conv_masking the heads see ALL tokens instead)
+    if not int(z["early_conv"]):
+        assert masked.shape[1] == z["cap/to_pixels_in"].shape[1] + z["cap/to_tactiles_in"].shape[1]
     assert unmasked.shape[1] == z["cap/encoder_in"].shape[1]
     both = np.sort(np.concatenate([masked, unmasked], 1), 1)
     assert np.array_equal(both, np.broadcast_to(np.arange(cfg.n_total), both.shape))
@@ -109,7 +110,7 @@ def test_backward_grads(golden_dir, name):
         assert P[u].grad is None, u
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
 def test_get_embeddings(golden_dir, name):
     z = _load(golden_dir, name)
     cfg = O.cfg_from_meta(z["meta"], z["ratio"])

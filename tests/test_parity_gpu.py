@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from m3l_amd import VTMAE, VTT  # noqa: E402
 from oracle import vtmae_oracle as O  # noqa: E402
 
-CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom"]
+CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv"]
 DEV = "cuda:0"
 
 
@@ -23,7 +23,7 @@ def build_from_fixture(z, compute_dtype="fp32"):
     enc = VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp, dim=dim, depth=depth,
               heads=heads, mlp_dim=mlp, image_channels=C, tactile_channels=C, num_tactiles=k)
     mae = VTMAE(encoder=enc, decoder_dim=dd, masking_ratio=float(z["ratio"]), decoder_depth=ddepth, decoder_heads=dheads,
-                num_tactiles=k, compute_dtype=compute_dtype)
+                num_tactiles=k, compute_dtype=compute_dtype, early_conv_masking=bool(int(z["early_conv"])))
     sd = {k_[len("param/"):]: torch.tensor(z[k_]) for k_ in z.files if k_.startswith("param/")}
     mae.load_state_dict(sd, strict=True)
     return mae.to(DEV)
@@ -84,7 +84,7 @@ def test_golden_fp32(golden_dir, name):
         assert dict(mae.named_parameters())[str(u)].grad is None, u
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
 def test_golden_bf16_loss(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     mae = build_from_fixture(z, compute_dtype="bf16")
@@ -99,7 +99,7 @@ def test_golden_bf16_loss(golden_dir, name):
     assert cos > 0.99, cos
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
 def test_golden_get_embeddings(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     mae = build_from_fixture(z)
@@ -293,3 +293,59 @@ def test_extractor_style_consumer_with_grad():
         assert float((g - gr).abs().max()) <= 5e-3 * float(gr.abs().max()) + 1e-8, name
     gh = head.layers[0][1].net[1].weight.grad.cpu()
     assert float((gh - PH["t.layers.0.1.net.1.weight"].grad).abs().max()) <= 5e-3 * float(gh.abs().max()) + 1e-8
+
+
+def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gtol=3e-3, seed=0):
+    torch.manual_seed(seed)
+    enc = VTT(**enc_kw)
+    mae = VTMAE(encoder=enc, **mae_kw).to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    x = {"image": torch.rand(B, C, hw_img, hw_img, generator=g).to(DEV)}
+    for i in range(k):
+        x[f"tactile{i + 1}"] = torch.rand(B, C, hw_tac, hw_tac, generator=g).to(DEV)
+    noises = [torch.rand(B, cfg.n_img, generator=g).to(DEV)] + [torch.rand(B, cfg.n_tac, generator=g).to(DEV) for _ in range(k)]
+    loss = mae(x, mask_noise=noises)
+    loss.backward()
+    P, r = _oracle_run(mae, cfg, x, noises)
+    assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"]) and torch.equal(mae.last_mask[1].cpu(), r["unmasked_indices"])
+    assert abs(float(loss.detach()) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss.detach()), float(r["loss"]))
+    for name, p in mae.named_parameters():
+        ref = P[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        err = float((p.grad.cpu() - ref).abs().max()) / max(1e-7, float(ref.abs().max()))
+        assert err <= gtol, (name, err)
+    return mae
+
+
+def test_reference_default_architecture():
+    """M3L's own defaults (train.py:58-67,128-153): dim 256 / depth 4 / heads 4 / mlp 512, decoder 256 / 3 / 4, mask 0.95,
+    early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row), at B = 3 and reduced depth."""
+    cfg = O.OracleCfg(64, 32, 8, 4, 256, 2, 4, 512, 12, 2, 256, 1, 4, 0.95)
+    _parity_vs_oracle(dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=256, depth=2, heads=4, mlp_dim=512,
+                           image_channels=12, tactile_channels=12, num_tactiles=2, frame_stack=4),
+                      dict(decoder_dim=256, masking_ratio=0.95, decoder_depth=1, decoder_heads=4, num_tactiles=2, early_conv_masking=True,
+                           frame_stack=4), B=3, C=12, hw_img=64, hw_tac=32, k=2, cfg=cfg)
+
+
+def test_cfg4_shapes():
+    """BASELINE cfg 4 geometry: 224x224 RGB (P16, 196 patches, pd 768) + 4 tactile 64x64 (P8), ViT-Small encoder 384 / 6 heads /
+    mlp 1536, decoder 192 / 3 heads (enc_to_dec projection, truncated decoder sincos), 452 tokens -> 113 visible; reduced depth."""
+    cfg = O.OracleCfg(224, 64, 16, 8, 384, 2, 6, 1536, 3, 4, 192, 1, 3, 0.75)
+    mae = _parity_vs_oracle(dict(image_size=224, tactile_size=64, image_patch_size=16, tactile_patch_size=8, dim=384, depth=2, heads=6,
+                                 mlp_dim=1536, num_tactiles=4),
+                            dict(decoder_dim=192, masking_ratio=0.75, decoder_depth=1, decoder_heads=3, num_tactiles=4),
+                            B=2, C=3, hw_img=224, hw_tac=64, k=4, cfg=cfg)
+    assert mae.last_mask[0].shape == (2, 339) and mae.last_mask[1].shape == (2, 113)
+
+
+def test_cfg5_shapes_patch14():
+    """BASELINE cfg 5 MAE geometry (train_dino_cat_mae.py:76,78,140-147): 70x70 frames, P = 14 (patch dim 588, not a multiple of
+    8 -> zero-padded K), 25 patches per modality, mask 0.8 -> 15 visible, 384 / 4 heads / mlp 768, decoder 384 / 4 heads."""
+    cfg = O.OracleCfg(70, 70, 14, 14, 384, 2, 4, 768, 3, 2, 384, 1, 4, 0.8)
+    mae = _parity_vs_oracle(dict(image_size=70, tactile_size=70, image_patch_size=14, tactile_patch_size=14, dim=384, depth=2, heads=4,
+                                 mlp_dim=768, num_tactiles=2),
+                            dict(decoder_dim=384, masking_ratio=0.8, decoder_depth=1, decoder_heads=4, num_tactiles=2),
+                            B=3, C=3, hw_img=70, hw_tac=70, k=2, cfg=cfg)
+    assert mae.last_mask[1].shape == (3, 15)

@@ -116,12 +116,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from m3l_amd import _lib
-    from m3l_amd.parallel import GradSync
+    from m3l_amd.parallel import FlatAdam, GradSync
     _lib.lib()
     c = CFG2
     mae = build_model(c, args.dtype, dev)
     sync = GradSync(mae)
-    opt = torch.optim.Adam(sync.params, lr=1e-4, fused=True)
+    opt = FlatAdam(sync, lr=1e-4)                 # torch.optim.Adam semantics, one HIP launch over the flat buffers
     B = args.batch
     torch.manual_seed(1234 + rank)
     x = {"image": torch.rand(B, 3, c["image_size"], c["image_size"], device=dev)}

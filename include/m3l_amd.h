@@ -132,6 +132,10 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream);
 
+/* ---- torch.optim.Adam semantics (models/ppo_mae.py:182-183) over one flat fp32 buffer of n elements; step counts from 1 */
+int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream);
+
 /* ---- in-library HIP-event timing of kernel classes (bench.py roofline).  filter: substring of "kind[AxBxC]" or NULL = all;
  * stride: bracket every stride-th matching launch (sampling keeps the perturbation of the timed region small). */
 void m3l_prof_begin(const char* filter, int stride);

@@ -174,11 +174,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-// up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment)
+// up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment).
+// 32 columns x 32 row-slices per 1024-thread block, 4 independent accumulators per thread: G = 2048 partial rows cost
+// 16 dependent load rounds instead of 64 (this reduce follows every LayerNorm backward: 34 launches per step).
 struct ReduceSegs { float* out[4]; };
-__global__ __launch_bounds__(256) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
-                                                                ReduceSegs segs, int accumulate) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
+                                                                 ReduceSegs segs, int accumulate) {
+    __shared__ float red[32][33];
     float* out = segs.out[blockIdx.y];
     if (!out) return;                            // uniform per block
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(256) void reduce_rows_seg_kernel(const float* __res
     if (j < width) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int g = sl;
-        for (; g + 24 < G; g += 32) {
+        for (; g + 96 < G; g += 128) {
             s0 += p[(long)g * stride + j];
-            s1 += p[(long)(g + 8) * stride + j];
-            s2 += p[(long)(g + 16) * stride + j];
-            s3 += p[(long)(g + 24) * stride + j];
+            s1 += p[(long)(g + 32) * stride + j];
+            s2 += p[(long)(g + 64) * stride + j];
+            s3 += p[(long)(g + 96) * stride + j];
         }
-        for (; g < G; g += 8) s0 += p[(long)g * stride + j];
+        for (; g < G; g += 32) s0 += p[(long)g * stride + j];
         s = (s0 + s1) + (s2 + s3);
     }
     red[sl][cl] = s;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void reduce_rows_seg_kernel(const float* __res
     if (sl == 0 && j < width) {
         float t = red[0][cl];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) t += red[i][cl];
+        for (int i = 1; i < 32; ++i) t += red[i][cl];
         out[j] = accumulate ? out[j] + t : t;
     }
 }
@@ -365,6 +367,36 @@ __global__ __launch_bounds__(256) void tokens_assemble_bwd_kernel(const float* _
     __syncthreads();
     for (int i = threadIdx.x; i < PL; i += 256)
         part[(long)blockIdx.x * PL + i] = sm[i] + sm[PL + i] + sm[2 * PL + i] + sm[3 * PL + i];
+}
+
+// Adam over ONE flat parameter / gradient / moment buffer (reference optimizer: torch.optim.Adam(mae.parameters(), lr=1e-4),
+// models/ppo_mae.py:182-183): same update rule and operation order as torch's, one launch for all 7.3 M parameters.
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] + wd * pp[j];
+            mm[j] = mm[j] + (gr - mm[j]) * (1.0f - b1);                 // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
+            vv[j] = vv[j] * b2 + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+            pp[j] = pp[j] - (lr / bc1) * (mm[j] / denom);
+        }
+        *reinterpret_cast<f32x4*>(p + i) = pp;
+        *reinterpret_cast<f32x4*>(m + i) = mm;
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+        for (long k = i; k < n; ++k) {
+            const float gr = g[k] + wd * p[k];
+            m[k] = m[k] + (gr - m[k]) * (1.0f - b1);
+            v[k] = v[k] * b2 + (1.0f - b2) * gr * gr;
+            p[k] = p[k] - (lr / bc1) * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
+        }
+    }
 }
 
 // vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW (normalisation [0,1] is the identity);
@@ -792,7 +824,7 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
     }
     M3L_LAUNCH_CHECK();
     ReduceSegs segs = {{dgamma, dbeta, dbias, nullptr}};
-    reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 3), 256, 0, st>>>(part_ws, G, 3 * D, D, segs, accumulate);
+    reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 3), 1024, 0, st>>>(part_ws, G, 3 * D, D, segs, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -882,6 +914,16 @@ int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac,
     tokens_assemble_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, B, D, n_img, n_tac > 0 ? n_tac : 1, k, d_img, d_tac, part_ws);
     M3L_LAUNCH_CHECK();
     reduce_rows_kernel<<<cdiv(PL, 32), 256, 0, st>>>(part_ws, G, PL, PL, dmod, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                  hipStream_t st) {
+    M3L_CHECK(n > 0 && step >= 1, "adam: n=%ld step=%d", n, step);
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
+    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
     M3L_LAUNCH_CHECK();
     return 0;
 }

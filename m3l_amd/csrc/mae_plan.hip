@@ -25,6 +25,31 @@ namespace {
 
 constexpr float LN_EPS = 1e-5f;
 
+// Side stream for work that is off the critical path of the backward (the grouped weight-gradient GEMMs): created once
+// per process and per device, joined to the caller's stream with events (fork / join — legal inside stream capture too).
+struct SideStream {
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> ev;
+    int next = 0;
+    int device = -1;
+};
+SideStream g_side;
+int side_init() {
+    int dev = 0;
+    M3L_HIP(hipGetDevice(&dev));
+    if (g_side.s && g_side.device == dev) return 0;
+    M3L_HIP(hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
+    g_side.device = dev;
+    g_side.ev.resize(64);
+    for (auto& e : g_side.ev) M3L_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
+}
+hipEvent_t side_event() {
+    hipEvent_t e = g_side.ev[g_side.next];
+    g_side.next = (g_side.next + 1) % (int)g_side.ev.size();
+    return e;
+}
+
 struct Arena {
     char* base;
     size_t off = 0;
@@ -122,7 +147,9 @@ struct TfLayer {
 struct TfWs {
     std::vector<TfLayer> L;
     float* dx;
-    void *dx_t, *dx1_t, *du, *dxn, *d_o, *dqkv;
+    void *dx_t[2], *dx1_t[2], *du[2], *dqkv[2];     // operands of the weight-gradient GEMMs: double-buffered by layer parity
+    void *dxn, *d_o;                                // (the wgrad of layer l runs on a side stream beside layer l-1's dgrads)
+    float* scratch_tn;
     float* dsum;
     float* scratch;
     float* scratch2;      // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue
@@ -150,12 +177,14 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
         l.xout = a.take_n<float>(M * D);
     }
     w.dx = a.take_n<float>(M * D);
-    w.dx_t = a.take(M * D * e);
-    w.dx1_t = a.take(M * D * e);
-    w.du = a.take(M * mlp * e);
+    for (int i = 0; i < 2; ++i) {
+        w.dx_t[i] = a.take(M * D * e);
+        w.dx1_t[i] = a.take(M * D * e);
+        w.du[i] = a.take(M * mlp * e);
+        w.dqkv[i] = a.take(M * 3 * HD * e);
+    }
     w.dxn = a.take(M * D * e);
     w.d_o = a.take(M * HD * e);
-    w.dqkv = a.take(M * 3 * HD * e);
     w.dsum = a.take_n<float>((size_t)B * c->heads * n);
     std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
     w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
@@ -167,6 +196,7 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
         w.scratch_b = std::max(w.scratch_b, m3l_gemm_tn_grouped_ws_bytes((int)M, pr, 4));
     }
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch2 = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
     w.total = a.off + 256;
     return w;
@@ -402,55 +432,75 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     // every ln_bwd also emits its result in the compute type (operand of the next GEMMs) and the column sums of it
     // (= bias gradient of the Linear that produced the residual branch): no separate cast / colsum passes.
     float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;       // fc2 bias of the last layer
-    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, w.dx_t, dt, w.scratch, gf[0], gf[1], db_last, 0, st))
+    const int top = (c->depth - 1) & 1;
+    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt, w.scratch,
+                   gf[0], gf[1], db_last, 0, st))
         return 1;
+    if (side_init()) return 2;
+    hipStream_t s2 = g_side.s;
+    hipEvent_t wg_done[2] = {nullptr, nullptr};       // completion of the wgrad that last read buffer set i
     const int csrows = m3l_gemm_nt_colsum_rows(M);
     for (int l = c->depth - 1; l >= 0; --l) {
         TfLayer& L = w.L[l];
+        const int cur = l & 1;
         const float* xl = l ? w.L[l - 1].xout : x_in;
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
+        // buffer set `cur` was last read by the side-stream wgrad of layer l+2: it must have finished before we overwrite it
+        // (dx_t[cur] was already written by layer l+1's last kernel, which waited on the same event — see below)
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
         GemmEpi e = epi0(mlp);
-        e.out_t = w.du; e.gelu_u = L.u; e.colsum_part = w.scratch2;
-        if (m3l_gemm_nt(dt, w.dx_t, D, L.w2T, D, M, mlp, D, &e, st)) return 1;                        // du = (dx W2) * gelu'(u)
+        e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2;
+        if (m3l_gemm_nt(dt, w.dx_t[cur], D, L.w2T, D, M, mlp, D, &e, st)) return 1;                   // du = (dx W2) * gelu'(u)
         if (m3l_reduce_rows(w.scratch2, csrows, mlp, mlp, g[8], 0, st)) return 1;                     // fc1 bias grad
         e = epi0(D);
         e.out_t = w.dxn;
-        if (m3l_gemm_nt(dt, w.du, mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                      // dxn2 = du W1
-        // dx1 = dx + LN2-backward (in place), + compute-type copy (own buffer: dx_t is still a wgrad operand), + out-proj bias grad
-        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t, dt, w.scratch, g[5], g[6],
+        if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                 // dxn2 = du W1
+        // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
+        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt, w.scratch, g[5], g[6],
                        c->project_out ? g[4] : nullptr, 0, st))
             return 1;
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
-        const void* d_o = w.dx1_t;
+        const void* d_o = w.dx1_t[cur];
         if (c->project_out) {
             e = epi0(HD);
             e.out_t = w.d_o;
-            if (m3l_gemm_nt(dt, w.dx1_t, D, L.woT, D, M, HD, D, &e, st)) return 1;                    // do = dx1 Wo
+            if (m3l_gemm_nt(dt, w.dx1_t[cur], D, L.woT, D, M, HD, D, &e, st)) return 1;               // do = dx1 Wo
             d_o = w.d_o;
         }
-        if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv, B, n, c->heads, st)) return 1;
-        e = epi0(D);
-        e.out_t = w.dxn;
-        if (m3l_gemm_nt(dt, w.dqkv, 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;         // dxn1 = dqkv Wqkv
-        // ---- all weight gradients of the layer in ONE grouped TN launch + one reduce
+        if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv[cur], B, n, c->heads, st)) return 1;
+        // ---- all weight gradients of the layer: ONE grouped TN launch + one reduce, on the side stream, overlapping the
+        // rest of this layer's and the next layer's dgrad chain (these kernels alone do not fill 256 CUs at M = B*48)
         {
+            hipEvent_t ready = side_event();
+            M3L_HIP(hipEventRecord(ready, st));
+            M3L_HIP(hipStreamWaitEvent(s2, ready, 0));
             TnProblem pr[4];
             memset(pr, 0, sizeof(pr));
             int np = 0;
-            pr[np++] = TnProblem{w.dx_t, L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0};                // dW2 = dx^T h
-            pr[np++] = TnProblem{w.du, L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};                  // dW1 = du^T xn2
-            pr[np++] = TnProblem{w.dqkv, L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0};      // dWqkv = dqkv^T xn1
-            if (c->project_out) pr[np++] = TnProblem{w.dx1_t, L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
-            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch, w.scratch_b, 0, st)) return 1;
+            pr[np++] = TnProblem{w.dx_t[cur], L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0};           // dW2 = dx^T h
+            pr[np++] = TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};             // dW1 = du^T xn2
+            pr[np++] = TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}; // dWqkv = dqkv^T xn1
+            if (c->project_out) pr[np++] = TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
+            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2)) return 1;
+            wg_done[cur] = side_event();
+            M3L_HIP(hipEventRecord(wg_done[cur], s2));
         }
+        e = epi0(D);
+        e.out_t = w.dxn;
+        if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
+        // the last kernel of this layer writes dx_t[cur^1] (and the next layer then du/dx1_t/dqkv[cur^1]): the wgrad of layer
+        // l+1, which reads that set, must be done
+        if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
         float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
         float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
-        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t : nullptr, dt, w.scratch, g[0], g[1],
+        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt, w.scratch, g[0], g[1],
                        db_prev, 0, st))
             return 1;
     }
+    // join: every weight gradient is complete before anything later on the caller's stream
+    for (int i = 0; i < 2; ++i)
+        if (wg_done[i]) M3L_HIP(hipStreamWaitEvent(st, wg_done[i], 0));
     if (c->depth == 0 && dx_in) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
@@ -839,6 +889,11 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream) {
     return m3l_vt_load_launch(image_nhwc, B, H, W, C, image_nchw, tactile, th, tw, n_sensors, frame_stack, tactile_out, (hipStream_t)stream);
+}
+
+int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream) {
+    return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,

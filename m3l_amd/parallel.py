@@ -45,6 +45,7 @@ class GradSync:
         total = sum(p.numel() for _, p in named)
         dev = named[0][1].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)     # parameters re-homed into one buffer too
         self.buckets = []                                      # (start, end, n_params)
         off, cur, start, count = 0, None, 0, 0
         self._bucket_index = {}
@@ -55,6 +56,9 @@ class GradSync:
             if b != cur:
                 self.buckets.append([start, off, count])
                 cur, start, count = b, off, 0
+            with torch.no_grad():
+                self.flat_params[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat_params[off:off + p.numel()].view_as(p)
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             self._bucket_index[id(p)] = len(self.buckets)
             off += p.numel()
@@ -99,3 +103,35 @@ class GradSync:
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) semantics (the reference's MAE optimizer, ppo_mae.py:182-183)
+    as ONE HIP launch over the GradSync's flat parameter / gradient buffers (m3l_adam_step)."""
+
+    def __init__(self, sync: GradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.sync, self.lr, self.betas, self.eps, self.weight_decay = sync, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(sync.flat)
+        self.exp_avg_sq = torch.zeros_like(sync.flat)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay, "params": sync.params}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.sync.zero_grad()
+
+    def step(self):
+        from . import _lib as L
+        self.step_count += 1
+        g = self.param_groups[0]
+        L.check(L.lib().m3l_adam_step(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                      g["eps"], g["weight_decay"], self.step_count, torch.cuda.current_stream().cuda_stream),
+                "m3l_adam_step")
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

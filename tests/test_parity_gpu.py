@@ -349,3 +349,31 @@ def test_cfg5_shapes_patch14():
                             dict(decoder_dim=384, masking_ratio=0.8, decoder_depth=1, decoder_heads=4, num_tactiles=2),
                             B=3, C=3, hw_img=70, hw_tac=70, k=2, cfg=cfg)
     assert mae.last_mask[1].shape == (3, 15)
+
+
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (one HIP launch over the flat parameter buffer) == torch.optim.Adam step for step (reference optimizer,
+    ppo_mae.py:182-183), including weight decay."""
+    from m3l_amd.parallel import FlatAdam, GradSync
+    torch.manual_seed(9)
+
+    def make():
+        torch.manual_seed(9)
+        enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128)
+        return VTMAE(encoder=enc, decoder_dim=64, decoder_depth=1, decoder_heads=2).to(DEV)
+    a, b = make(), make()
+    sync = GradSync(a)
+    oa = FlatAdam(sync, lr=3e-3, weight_decay=0.01)
+    names = [n for n, p in b.named_parameters() if n not in GradSync.SKIP]
+    ob = torch.optim.Adam([dict(b.named_parameters())[n] for n in names], lr=3e-3, weight_decay=0.01)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for _ in range(4):
+        grads = {n: torch.randn(dict(b.named_parameters())[n].shape, generator=g).to(DEV) for n in names}
+        for n in names:
+            dict(a.named_parameters())[n].grad.copy_(grads[n])
+            dict(b.named_parameters())[n].grad = grads[n].clone()
+        oa.step()
+        ob.step()
+    for n in names:
+        pa, pb = dict(a.named_parameters())[n], dict(b.named_parameters())[n]
+        assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max())), n

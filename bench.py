@@ -4,7 +4,8 @@
 batch 256 per GPU, bf16 compute), synthetic random frames, random-init weights.
 
 One "step" = zero_grad + mask sampling + VTMAE forward + backward (+ RCCL gradient all-reduce when N > 1)
-+ Adam(lr=1e-4) update (reference: models/ppo_mae.py:182-183,262-266).  Weak scaling: 256 samples per GPU.
++ Adam(lr=1e-4) update (reference: models/ppo_mae.py:182-183,262-266; the update runs as ONE HIP launch over the flat
+parameter buffer, m3l_amd.parallel.FlatAdam, numerically torch.optim.Adam).  Weak scaling: 256 samples per GPU.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -142,6 +143,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):            # priming, always: code-object load, allocator growth, side stream / event pool creation
+        step()
     for _ in range(args.warmup):
         step()
     lib = _lib.lib()
@@ -174,7 +177,7 @@ def main():
         import ctypes as C
         # ---- roofline of the dominant kernel (HIP events recorded by the library around its launches, inside the timed
         # region, on the launch stream).  The dominant kernel of this step is the LDS-DMA MFMA GEMM instantiation
-        # gemm_nt_glds_kernel<bf16,64> (all N=192 / N=576 linears and dgrads): skinny K (192..768) makes it HBM-bound
+        # gemm_nt_glds_kernel<bf16,64,3> (every Linear forward and dgrad): skinny K (192..768) makes it HBM-bound
         # (38..150 FLOP/byte < 2500 TFLOP/s / 8 TB/s = 312 FLOP/byte), so it is priced against the HBM roof; the MFMA
         # rate it reaches is reported beside it.
         n = lib.m3l_prof_count()
@@ -198,7 +201,7 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get(kname, {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": {"gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64>", "gemm_nt_glds128": "gemm_nt_glds_kernel<bf16,128>"}.get(kname, kname),
+            out["roofline"] = {"kernel": {"gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,3>"}.get(kname, kname),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                                "traffic": traffic, "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2),
                                "launches_sampled": launches,

@@ -8,6 +8,7 @@
 // Tile: 128 x 128 per 256-thread workgroup (2x2 waves of 64x64 = 4x4 MFMA tiles), register-staged double-buffered
 // LDS (global_load_dwordx4 issued before the MFMA block, ds_write after it: guide T14), epilogue staged through LDS
 // so that every global store is a 16-byte row segment.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.cuh"
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // and again on the fragment read (guide rule 21) -> conflict-free ds_read_b128.  Two stages; the next K-tile's DMA is
 // issued before the MFMA block of the current one.  Needs K % (128 / sizeof(T)) == 0; rows past M / N are clamped (their
 // products are never stored).
-template <typename T, int BN>
+template <typename T, int BN, int R>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              int M, int N, int K, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,12 +239,31 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // R-deep ring of K-tiles.  R == 2: classic double buffer (the barrier's vmcnt(0) drains the prefetch, so only one DMA
+    // latency is hidden per tile).  R == 3: two tiles stay in flight across the barrier — counted s_waitcnt vmcnt(N) + raw
+    // s_barrier (guide "Pipelining across barriers"): with K = 192 (3 tiles) the whole panel is requested up front and the
+    // workgroup pays ONE DMA latency instead of three.
+    constexpr int DMA_PER_STAGE = 4 + BSEG;        // LDS-DMA instructions per wave and K-tile
     const int nk = K / BKE;
     stage(0, 0);
-    __syncthreads();                               // vmcnt(0) + barrier: tile 0 landed for every wave
+    if (R == 3 && nk > 1) stage(1, BKE);
+    if (R == 2) __syncthreads();                   // vmcnt(0) + barrier: tile 0 landed for every wave
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BKE);
+        int cur;
+        if (R == 2) {
+            cur = t & 1;
+            if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BKE);
+        } else {
+            cur = t % 3;
+            if (t + 1 < nk) {
+                if (DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();          // tile t landed for every wave; every wave is done reading tile t-1
+            if (t + 2 < nk) stage((t + 2) % 3, (t + 2) * BKE);
+        }
         const char* As = smem + cur * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
@@ -258,8 +278,9 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
         }
-        __syncthreads();                           // next tile landed (vmcnt(0)) and this one fully read
+        if (R == 2) __syncthreads();               // next tile landed (vmcnt(0)) and this one fully read
     }
+    if (R == 3) __syncthreads();                   // all tiles consumed before the stages are reused by the epilogue
 
     // ---- epilogue: accumulators -> LDS (f32) -> 16-byte row segments -----------------------------------------
     float* Cs = reinterpret_cast<float*>(smem);
@@ -626,19 +647,19 @@ __global__ void reduce_splits_grouped_kernel(TnGroup grp, const float* __restric
 
 }  // namespace
 
-static constexpr int glds_lds_bytes(int bn) {
-    const int stages = 2 * (128 * 128 + bn * 128), cs = 128 * (bn + 4) * 4;
-    return (stages > cs ? stages : cs) + (256 / (bn / 8)) * bn * 4;
+static constexpr int glds_lds_bytes(int bn, int r = 2) {
+    const int stages = r * (128 * 128 + bn * 128), cs = 128 * (bn + 4) * 4 + (256 / (bn / 8)) * bn * 4;
+    return stages > cs ? stages : cs;
 }
 static int g_gemm_inited = 0;
 int m3l_gemm_init() {
     if (g_gemm_inited) return 0;
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 3)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 3)));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
@@ -663,21 +684,22 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     const double bytes = (double)M * K * es + (double)N * K * es +
                          (double)M * N * ((epi->res ? 4.0 : 0.0) + (epi->out_f32 ? 4.0 : 0.0) + (epi->out_t ? es : 0.0) +
                                           (epi->out_pre ? es : 0.0) + (epi->gelu_u ? es : 0.0));
-    const char* kind = (K % bke != 0) ? "gemm_nt_generic" : ((N % 128 == 0 || N >= 1024) ? "gemm_nt_glds128" : "gemm_nt_glds64");
+    const char* kind = (K % bke != 0) ? "gemm_nt_generic" : "gemm_nt_glds64";
     ProfScope prof(kind, M, N, K, 2.0 * M * N * K, st, bytes);
     if (K % bke == 0) {
-        if (N % 128 == 0 || N >= 1024) {
+        static const bool wide = getenv("M3L_GEMM_BN128") != nullptr;      // A/B switch for the micro-benchmark
+        if (wide && (N % 128 == 0 || N >= 1024)) {
             dim3 grid(8 * cdiv(N, 128) * cdiv(cdiv(M, 128), 8));
             if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<bf16, 128, 2><<<grid, 256, glds_lds_bytes(128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
-                gemm_nt_glds_kernel<float, 128><<<grid, 256, glds_lds_bytes(128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<float, 128, 2><<<grid, 256, glds_lds_bytes(128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
         } else {
             dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 128), 8));
             if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 64><<<grid, 256, glds_lds_bytes(64), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<bf16, 64, 3><<<grid, 256, glds_lds_bytes(64, 3), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
-                gemm_nt_glds_kernel<float, 64><<<grid, 256, glds_lds_bytes(64), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<float, 64, 3><<<grid, 256, glds_lds_bytes(64, 3), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
         }
     } else {
         M3L_CHECK(epi->colsum_part == nullptr, "gemm_nt: colsum epilogue needs K %% %d == 0", bke);

@@ -140,6 +140,7 @@ int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * stride: bracket every stride-th matching launch (sampling keeps the perturbation of the timed region small). */
 void m3l_prof_begin(const char* filter, int stride);
 void m3l_prof_end(void);
+double m3l_prof_event_overhead_us(void* stream, int n);   /* median cost of an EMPTY event bracket (no kernel between) */
 int m3l_prof_count(void);
 int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* flops_total, double* bytes_total);
 

@@ -61,6 +61,7 @@ _SIGS = {
     "m3l_adam_step": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, c_p]),
     "m3l_prof_begin": (None, [C.c_char_p, c_i]),
     "m3l_prof_end": (None, []),
+    "m3l_prof_event_overhead_us": (C.c_double, [c_p, c_i]),
     "m3l_prof_count": (c_i, []),
     "m3l_prof_get": (c_i, [c_i, C.c_char_p, c_sz, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double),
                            C.POINTER(C.c_double)]),

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -92,6 +93,24 @@ void m3l_prof_end(void) {
         g_pool.push_back(r.b);
     }
     g_recs.clear();
+}
+// cost of one empty event bracket on `stream` (record, record, nothing between), median of n: the fixed part of every
+// bracketed launch that is not kernel time (subtract it before comparing with rocprofv3's in-kernel durations)
+double m3l_prof_event_overhead_us(void* stream, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1) n = 1;
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) e = get_event();
+    for (int i = 0; i < n; ++i) {
+        hipEventRecord(ev[2 * i], st);
+        hipEventRecord(ev[2 * i + 1], st);
+    }
+    hipStreamSynchronize(st);
+    std::vector<float> ms(n, 0.f);
+    for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]);
+    for (auto& e : ev) g_pool.push_back(e);
+    std::sort(ms.begin(), ms.end());
+    return 1e3 * ms[n / 2];
 }
 int m3l_prof_count(void) { return (int)g_cls.size(); }
 int m3l_prof_get(int i, char* name, size_t n, double* ms_total, long* launches, double* work_total, double* bytes_total) {

@@ -77,6 +77,11 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
 int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
                         int dy_dtype, float* dx_in, float* const* grads, void* stream);
 
+/* the same, restricted to layers [layer_lo, layer_hi) (descending): lets the caller interleave the gradient all-reduce of finished
+ * layers with the backward of the remaining ones.  Call with layer_hi == depth first (consumes dy), down to layer_lo == 0. */
+int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws,
+                              const void* dy, int dy_dtype, float* dx_in, float* const* grads, int layer_hi, int layer_lo, void* stream);
+
 /* ---- encoder -> decoder glue.  enc32 / enc_t: final-norm output of the encoder (B, nvis, D) in f32 / compute type.
  * tensors: {e2d_w[dd,D] or NULL, e2d_b or NULL, mask_token[dd], dec_mod[(1+k),dd], pos_img_dec[n_img,dd], pos_tac_dec[k*n_tac,dd]} */
 size_t m3l_unshuffle_ws_bytes(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask);

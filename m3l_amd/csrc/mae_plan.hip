@@ -421,7 +421,17 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
 
 int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
                         int dy_dtype, float* dx_in, float* const* grads, void* stream) {
+    return m3l_transformer_bwd_range(c, B, n, x_in, tensors, ws, dy, dy_dtype, dx_in, grads, c->depth, 0, stream);
+}
+
+// Backward of layers [layer_lo, layer_hi), descending.  layer_hi == depth also runs the final-norm backward (consumes dy);
+// layer_lo == 0 writes dx_in.  The running residual gradient lives in the workspace between calls, so a caller can split the
+// backward into chunks and start the gradient all-reduce of a chunk while the next one computes.  On return every gradient of
+// the layers in the range (and fc2.bias of layer_lo - 1) is ordered on `stream`.
+int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
+                              int dy_dtype, float* dx_in, float* const* grads, int layer_hi, int layer_lo, void* stream) {
     if (check_tf(c, B, n)) return 1;
+    M3L_CHECK(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= c->depth, "transformer_bwd: bad layer range [%d, %d)", layer_lo, layer_hi);
     M3L_CHECK(dy_dtype == 0 || dy_dtype == c->dtype, "transformer_bwd: dy dtype %d incompatible with compute dtype %d", dy_dtype, c->dtype);
     hipStream_t st = (hipStream_t)stream;
     TfWs w = tf_layout(c, B, n, ws);
@@ -431,16 +441,18 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     float* const* gf = grads + 11 * c->depth;
     // every ln_bwd also emits its result in the compute type (operand of the next GEMMs) and the column sums of it
     // (= bias gradient of the Linear that produced the residual branch): no separate cast / colsum passes.
-    float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;       // fc2 bias of the last layer
-    const int top = (c->depth - 1) & 1;
-    if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt, w.scratch,
-                   gf[0], gf[1], db_last, 0, st))
-        return 1;
+    if (layer_hi == c->depth) {
+        float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;   // fc2 bias of the last layer
+        const int top = (c->depth - 1) & 1;
+        if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt, w.scratch,
+                       gf[0], gf[1], db_last, 0, st))
+            return 1;
+    }
     if (side_init()) return 2;
     hipStream_t s2 = g_side.s;
     hipEvent_t wg_done[2] = {nullptr, nullptr};       // completion of the wgrad that last read buffer set i
     const int csrows = m3l_gemm_nt_colsum_rows(M);
-    for (int l = c->depth - 1; l >= 0; --l) {
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
         TfLayer& L = w.L[l];
         const int cur = l & 1;
         const float* xl = l ? w.L[l - 1].xout : x_in;
@@ -501,7 +513,7 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     // join: every weight gradient is complete before anything later on the caller's stream
     for (int i = 0; i < 2; ++i)
         if (wg_done[i]) M3L_HIP(hipStreamWaitEvent(st, wg_done[i], 0));
-    if (c->depth == 0 && dx_in) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (c->depth == 0 && dx_in && layer_hi == 0) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -15,6 +15,10 @@ from . import _lib as L
 
 DT_F32, DT_BF16 = 0, 1
 
+# Layers per backward chunk of a transformer stack (None: one call).  With a GradSync on more than one rank the chunks let the
+# all-reduce of finished layers travel while the remaining layers compute; tests set it to exercise the range entry point.
+BWD_CHUNK_LAYERS = None
+
 
 def dtype_code(compute_dtype) -> int:
     if compute_dtype in ("bf16", torch.bfloat16, 1):
@@ -169,10 +173,26 @@ class TransformerFn(torch.autograd.Function):
             dy, code = _f32c(dy32), DT_F32
         grads = _grad_targets(ctx.sink, ctx.params)
         dx = torch.empty_like(x)
-        L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
-                                            L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
-        _done(ctx.sink)
-        return (None, None, dx) + _returned(ctx.sink, grads)
+        sink = ctx.sink
+        chunk = BWD_CHUNK_LAYERS
+        if chunk is None and sink is not None and sink[1] is not None and sink[0].world > 1:
+            chunk = sink[0].layers_per_chunk
+        if not chunk or chunk >= cfg.depth:
+            L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
+                                                L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
+            _done(sink)
+        else:
+            tens_a, grads_a = L.ptr_array(tens), L.ptr_array(grads)
+            hi = cfg.depth
+            while hi > 0:
+                lo = max(0, hi - chunk)
+                L.check(L.lib().m3l_transformer_bwd_range(C.byref(cfg), B, n, L.ptr(x), tens_a, L.ptr(ws), L.ptr(dy), code, L.ptr(dx),
+                                                          grads_a, hi, lo, _stream()), "m3l_transformer_bwd_range")
+                if sink is not None and sink[1] is not None:
+                    done = list(ctx.params[11 * lo:11 * hi]) + (list(ctx.params[11 * cfg.depth:]) if hi == cfg.depth else [])
+                    sink[0].range_done(sink[1], done, last=(lo == 0))
+                hi = lo
+        return (None, None, dx) + _returned(sink, grads)
 
 
 class UnshuffleFn(torch.autograd.Function):

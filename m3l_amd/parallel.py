@@ -11,6 +11,8 @@ torch.distributed (backend "nccl" == RCCL on ROCm) runs it on its own HIP stream
 stream — so the decoder's 7 MB travel while the encoder backward is still computing.  Parameters that never receive a
 gradient under sincos encodings (encoder.pos_embedding, decoder_pos_emb) are excluded (`grad is None`).
 """
+import re
+
 import torch
 import torch.distributed as dist
 
@@ -27,6 +29,14 @@ def _bucket_of(name: str) -> int:
     return 4        # patch embed / EarlyCNN stems, encoder modality embedding
 
 
+def _layer_of(name: str) -> int:
+    m = re.search(r"\.layers\.(\d+)\.", name)
+    if m:
+        return int(m.group(1))
+    return 1 << 30 if (name.endswith("transformer.norm.weight") or name.endswith("transformer.norm.bias")
+                       or name in ("decoder.norm.weight", "decoder.norm.bias")) else 0
+
+
 class GradSync:
     """Flat-buffer, bucketed, backward-overlapped gradient all-reduce (average)."""
 
@@ -41,11 +51,15 @@ class GradSync:
                 continue
             seen.add(id(p))
             named.append((name, p))
-        named.sort(key=lambda np_: _bucket_of(np_[0]))        # stable: keeps definition order inside a bucket
+        # buckets in backward order; inside a transformer bucket: final norm first, then layers from the top down (the order the
+        # backward finishes them), so that a chunk of layers is one contiguous slice of the flat buffer
+        named.sort(key=lambda np_: (_bucket_of(np_[0]), -_layer_of(np_[0])))
         total = sum(p.numel() for _, p in named)
         dev = named[0][1].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)     # parameters re-homed into one buffer too
+        self.layers_per_chunk = 4                              # transformer backward chunk size for comm / compute overlap
+        self._span = {}                                        # id(param) -> (start, end) in the flat buffer
         self.buckets = []                                      # (start, end, n_params)
         off, cur, start, count = 0, None, 0, 0
         self._bucket_index = {}
@@ -60,6 +74,7 @@ class GradSync:
                 self.flat_params[off:off + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.flat_params[off:off + p.numel()].view_as(p)
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._span[id(p)] = (off, off + p.numel())
             self._bucket_index[id(p)] = len(self.buckets)
             off += p.numel()
             count += 1
@@ -84,6 +99,16 @@ class GradSync:
         if self.world <= 1 or bucket_id not in self._bucket_ids:
             return
         s, e, _ = self.buckets[self._bucket_ids.index(bucket_id)]
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def range_done(self, bucket_id: int, params, last: bool):
+        """Part of a bucket is final (a chunk of transformer layers): all-reduce just that contiguous slice."""
+        spans = [self._span[id(p)] for p in params if p is not None and id(p) in self._span]
+        if last:
+            self._reduced.add(bucket_id)
+        if self.world <= 1 or not spans:
+            return
+        s, e = min(a for a, _ in spans), max(b for _, b in spans)
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):

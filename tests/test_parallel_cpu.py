@@ -46,6 +46,17 @@ def _worker(rank, world, port, ret):
         s, e, _ = sync.buckets[sync._bucket_ids.index(b)]
         expect = (b + 1) * sum(r + 1 for r in range(world)) / world
         assert torch.allclose(sync.flat[s:e], torch.full((e - s,), expect)), (b, float(sync.flat[s]), expect)
+    # chunked transformer bucket: layers are laid out top-down, a chunk is one contiguous slice, only that slice is reduced
+    sync.zero_grad()
+    enc_params = [p for n_, p in mae.named_parameters() if n_.startswith("encoder.transformer")]
+    spans = sorted(sync._span[id(p)] for p in enc_params)
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    norm_w = dict(mae.named_parameters())["encoder.transformer.norm.weight"]
+    assert sync._span[id(norm_w)][0] == spans[0][0]                       # final norm first (its backward runs first)
+    sync.flat.fill_(float(rank + 1))
+    sync.range_done(3, enc_params, last=True)
+    sync.finish()       # also reduces the buckets nobody reported
+    assert torch.allclose(sync.flat, torch.full_like(sync.flat, 1.5))
     # parameters see the reduced values through their .grad views
     assert float(mae.to_pixels.weight.grad[0, 0]) == 1.5
     ret[rank] = float(sync.flat.sum())

@@ -377,3 +377,28 @@ def test_flat_adam_matches_torch_adam():
     for n in names:
         pa, pb = dict(a.named_parameters())[n], dict(b.named_parameters())[n]
         assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max())), n
+
+
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_chunked_transformer_backward_is_bit_identical(chunk):
+    """m3l_transformer_bwd_range: splitting the backward into layer chunks (used to overlap the RCCL all-reduce of finished layers
+    with the remaining backward) must not change a single bit of any gradient."""
+    from m3l_amd import functional as Fn
+    torch.manual_seed(21)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=3, heads=2, mlp_dim=128)
+    mae = VTMAE(encoder=enc, decoder_dim=64, decoder_depth=2, decoder_heads=2, compute_dtype="bf16").to(DEV)
+    B = 4
+    x = {"image": torch.rand(B, 3, 32, 32, device=DEV), "tactile1": torch.rand(B, 3, 16, 16, device=DEV),
+         "tactile2": torch.rand(B, 3, 16, 16, device=DEV)}
+    noises = [torch.rand(B, 16, device=DEV) for _ in range(3)]
+    mae(x, mask_noise=noises).backward()
+    ref = {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}
+    mae.zero_grad(set_to_none=True)
+    try:
+        Fn.BWD_CHUNK_LAYERS = chunk
+        mae(x, mask_noise=noises).backward()
+    finally:
+        Fn.BWD_CHUNK_LAYERS = None
+    for n, p in mae.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), n

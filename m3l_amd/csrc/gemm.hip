@@ -627,8 +627,20 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int S, i
 }
 
 __global__ void reduce_splits_grouped_kernel(TnGroup grp, const float* __restrict__ partial_base, int S, int accumulate) {
-    const TnProblem& pb = grp.p[blockIdx.y];
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)blockIdx.y == grp.count) {          // the extra column reduction (bias gradient partials)
+        if (idx >= grp.extra_width) return;
+        float s0 = 0.f, s1 = 0.f;
+        int g = 0;
+        for (; g + 1 < grp.extra_G; g += 2) {
+            s0 += grp.extra_part[(long)g * grp.extra_width + idx];
+            s1 += grp.extra_part[(long)(g + 1) * grp.extra_width + idx];
+        }
+        if (g < grp.extra_G) s0 += grp.extra_part[(long)g * grp.extra_width + idx];
+        grp.extra_out[idx] = accumulate ? grp.extra_out[idx] + (s0 + s1) : (s0 + s1);
+        return;
+    }
+    const TnProblem& pb = grp.p[blockIdx.y];
     const long cnt = (long)pb.N * pb.K;
     if (idx >= cnt) return;
     const int n = (int)(idx / pb.K), k = (int)(idx % pb.K);
@@ -740,7 +752,7 @@ size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count) {
 }
 
 int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, const float* extra_part, int extra_G, int extra_width, float* extra_out) {
     if (m3l_gemm_init()) return 2;
     M3L_CHECK(dtype == 0 || dtype == 1, "gemm_tn: bad dtype %d", dtype);
     M3L_CHECK(count >= 1 && count <= 4 && M > 0, "gemm_tn_grouped: count=%d M=%d", count, M);
@@ -772,6 +784,11 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
     }
     grp.count = count;
     grp.tiles_total = tiles;
+    const bool extra = extra_part && extra_out && extra_G > 0 && extra_width > 0;
+    if (extra) {
+        grp.extra_part = extra_part; grp.extra_out = extra_out; grp.extra_G = extra_G; grp.extra_width = extra_width;
+        if (extra_width > maxnk) maxnk = extra_width;
+    }
     M3L_CHECK(ws_bytes >= (size_t)off * sizeof(float), "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, (size_t)off * sizeof(float));
     {
         ProfScope prof("gemm_tn", M, tiles, S, flops, st, bytes + (double)off * 4.0);
@@ -783,7 +800,7 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
     }
     M3L_LAUNCH_CHECK();
     ProfScope prof2("gemm_tn_reduce", S, tiles, count, 0.0, st, (double)off * 4.0);
-    reduce_splits_grouped_kernel<<<dim3(cdiv(maxnk, 256), count), 256, 0, st>>>(grp, partial_ws, S, accumulate);
+    reduce_splits_grouped_kernel<<<dim3(cdiv(maxnk, 256), count + (extra ? 1 : 0)), 256, 0, st>>>(grp, partial_ws, S, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }

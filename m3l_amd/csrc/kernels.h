@@ -71,10 +71,16 @@ struct TnProblem {
 struct TnGroup {
     TnProblem p[4];
     int count, tiles_total;
+    // optional extra column reduction carried by the group's reduce launch: out[j] = sum_g part[g*width + j]
+    // (the fc1 bias gradient: per-row-block column sums written by the fused dgrad epilogue)
+    const float* extra_part;
+    float* extra_out;
+    int extra_G, extra_width;
 };
 size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count);
 int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
-                        hipStream_t st);
+                        hipStream_t st, const float* extra_part = nullptr, int extra_G = 0, int extra_width = 0,
+                        float* extra_out = nullptr);
 int m3l_gemm_init();
 int m3l_gemm_nt_colsum_rows(int M);   // number of partial rows written through GemmEpi::colsum_part
 

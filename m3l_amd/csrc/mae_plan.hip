@@ -152,7 +152,7 @@ struct TfWs {
     float* scratch_tn;
     float* dsum;
     float* scratch;
-    float* scratch2;      // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue
+    float* scratch2[2];   // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue (double-buffered like the wgrad operands)
     size_t scratch_b;
     size_t total;
 };
@@ -197,7 +197,7 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     }
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
-    w.scratch2 = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
+    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
     w.total = a.off + 256;
     return w;
 }
@@ -379,20 +379,38 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     TfWs w = tf_layout(c, B, n, ws);
     const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
     const float* x = x_in;
+    // compute-type weight copies (+ transposes for the dgrads): layer 0 on the caller's stream, layers 1.. on the side stream
+    // while layer 0 computes (fork after everything already queued on `st`, e.g. the optimizer step; join before layer 1)
+    auto prep_layer = [&](int l, hipStream_t ps) -> int {
+        TfLayer& L = w.L[l];
+        const void* const* t = tensors + 11 * l;
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.d[0] = WeightDesc{(const float*)t[2], L.wqkv, L.wqkvT, 3 * HD, D, D, 3 * HD};
+        pk.d[1] = WeightDesc{(const float*)t[7], L.w1, L.w1T, mlp, D, D, mlp};
+        pk.d[2] = WeightDesc{(const float*)t[9], L.w2, L.w2T, D, mlp, mlp, D};
+        pk.count = 3;
+        if (c->project_out) pk.d[pk.count++] = WeightDesc{(const float*)t[3], L.wo, L.woT, D, HD, HD, D};
+        return m3l_prep_weights(dt, &pk, ps);
+    };
+    hipEvent_t prep_done = nullptr;
+    if (c->depth > 0 && prep_layer(0, st)) return 1;
+    if (c->depth > 1) {
+        if (side_init()) return 2;
+        hipEvent_t fork = side_event();
+        M3L_HIP(hipEventRecord(fork, st));
+        M3L_HIP(hipStreamWaitEvent(g_side.s, fork, 0));
+        for (int l = 1; l < c->depth; ++l)
+            if (prep_layer(l, g_side.s)) return 1;
+        prep_done = side_event();
+        M3L_HIP(hipEventRecord(prep_done, g_side.s));
+    }
     for (int l = 0; l < c->depth; ++l) {
         TfLayer& L = w.L[l];
         const void* const* t = tensors + 11 * l;
-        const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *qkv_w = (const float*)t[2], *out_w = (const float*)t[3],
-                    *out_b = (const float*)t[4], *ln2_w = (const float*)t[5], *ln2_b = (const float*)t[6], *fc1_w = (const float*)t[7],
-                    *fc1_b = (const float*)t[8], *fc2_w = (const float*)t[9], *fc2_b = (const float*)t[10];
-        WeightPack pk;
-        memset(&pk, 0, sizeof(pk));
-        pk.d[0] = WeightDesc{qkv_w, L.wqkv, L.wqkvT, 3 * HD, D, D, 3 * HD};
-        pk.d[1] = WeightDesc{fc1_w, L.w1, L.w1T, mlp, D, D, mlp};
-        pk.d[2] = WeightDesc{fc2_w, L.w2, L.w2T, D, mlp, mlp, D};
-        pk.count = 3;
-        if (c->project_out) pk.d[pk.count++] = WeightDesc{out_w, L.wo, L.woT, D, HD, HD, D};
-        if (m3l_prep_weights(dt, &pk, st)) return 1;
+        const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *out_b = (const float*)t[4], *ln2_w = (const float*)t[5],
+                    *ln2_b = (const float*)t[6], *fc1_b = (const float*)t[8], *fc2_b = (const float*)t[10];
+        if (l == 1 && prep_done) M3L_HIP(hipStreamWaitEvent(st, prep_done, 0));
 
         if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
         GemmEpi e = epi0(3 * HD);
@@ -462,9 +480,9 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         // (dx_t[cur] was already written by layer l+1's last kernel, which waited on the same event — see below)
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
         GemmEpi e = epi0(mlp);
-        e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2;
+        e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2[cur];
         if (m3l_gemm_nt(dt, w.dx_t[cur], D, L.w2T, D, M, mlp, D, &e, st)) return 1;                   // du = (dx W2) * gelu'(u)
-        if (m3l_reduce_rows(w.scratch2, csrows, mlp, mlp, g[8], 0, st)) return 1;                     // fc1 bias grad
+        // (the per-row-block column sums in scratch2[cur] = fc1 bias gradient partials are reduced by the wgrad group's reduce)
         e = epi0(D);
         e.out_t = w.dxn;
         if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                 // dxn2 = du W1
@@ -494,7 +512,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             pr[np++] = TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};             // dW1 = du^T xn2
             pr[np++] = TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}; // dWqkv = dqkv^T xn1
             if (c->project_out) pr[np++] = TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
-            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2)) return 1;
+            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2, w.scratch2[cur], csrows, mlp, g[8])) return 1;
             wg_done[cur] = side_event();
             M3L_HIP(hipEventRecord(wg_done[cur], s2));
         }

@@ -185,7 +185,7 @@ def main():
         import ctypes as C
         # ---- roofline of the dominant kernel (HIP events recorded by the library around its launches, inside the timed
         # region, on the launch stream).  The dominant kernel of this step is the LDS-DMA MFMA GEMM instantiation
-        # gemm_nt_glds_kernel<bf16,64,3> (every Linear forward and dgrad): skinny K (192..768) makes it HBM-bound
+        # gemm_nt_glds_kernel<bf16,64,2,*> (every Linear forward and dgrad): skinny K (192..768) makes it HBM-bound
         # (38..150 FLOP/byte < 2500 TFLOP/s / 8 TB/s = 312 FLOP/byte), so it is priced against the HBM roof; the MFMA
         # rate it reaches is reported beside it.
         n = lib.m3l_prof_count()
@@ -210,7 +210,7 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get(kname, {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": {"gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,3>"}.get(kname, kname),
+            out["roofline"] = {"kernel": {"gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                                "traffic": traffic, "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2), "avg_bracket_us_raw": round(raw_us, 2), "event_bracket_overhead_us": round(ev_overhead_us, 2),
                                "launches_sampled": launches,

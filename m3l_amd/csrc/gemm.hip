@@ -169,15 +169,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // and again on the fragment read (guide rule 21) -> conflict-free ds_read_b128.  Two stages; the next K-tile's DMA is
 // issued before the MFMA block of the current one.  Needs K % (128 / sizeof(T)) == 0; rows past M / N are clamped (their
 // products are never stored).
-template <typename T, int BN, int R>
+template <typename T, int BN, int R, int BM = 128>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              int M, int N, int K, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Chunk<T>::N;             // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;                 // elements per 128-byte LDS row (K-tile depth): 64 bf16 / 32 f32
     constexpr int KSTEPS = BKE / 32;             // MFMA macro steps per K-tile
-    constexpr int A_BYTES = 128 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int WM = (BN == 128) ? 64 : 32;    // rows per wave: 2x2 waves of 64x64, or 4x1 waves of 32x64
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = (BN == 128) ? BM / 2 : BM / 4;   // rows per wave: 2x2 waves (BN = 128) or 4x1 waves (BN = 64), 64 columns each
+    constexpr int ASEG = BM / 32;                // 1-KiB A segments (8 rows) per wave and K-tile
     constexpr int TM = WM / 16;
     constexpr int CSLD = BN + 4;
     typedef __attribute__((address_space(3))) void* lds_vp;
@@ -189,18 +190,18 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     // XCD-aware tile order (guide T1): workgroup ids are dealt round-robin over the 8 XCDs, so ids that differ by a
     // multiple of 8 share an L2.  All column tiles of one 128-row block get ids b, b+8, b+16, ... -> the A rows they
     // share are fetched from HBM once per XCD-L2 instead of once per column tile.  Placement only affects speed.
-    const int gx = (N + BN - 1) / BN, gy = (M + 127) / 128;
+    const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int bid = blockIdx.x, rest = bid >> 3;
     const int bx = rest % gx, by = (rest / gx) * 8 + (bid & 7);
     if (by >= gy) return;
-    const int m0 = by * 128, n0 = bx * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
     // per-lane source pointers of this wave's DMA segments (1 KiB = 8 rows x 8 chunks each)
     const int srow = lane >> 3, spc = lane & 7;
-    const T* asrc[4];
+    const T* asrc[ASEG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + srow;
+    for (int i = 0; i < ASEG; ++i) {
+        const int row = (wave * ASEG + i) * 8 + srow;
         asrc[i] = A + (long)min(m0 + row, M - 1) * lda + (spc ^ (row & 7)) * EPC;
     }
     constexpr int BSEG = BN / 32;                // B segments per wave: 4 (BN=128) or 2 (BN=64)
@@ -213,8 +214,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     auto stage = [&](int st, int k0) {
         char* base = smem + st * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gl_vp)(asrc[i] + k0), (lds_vp)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < ASEG; ++i)
+            __builtin_amdgcn_global_load_lds((gl_vp)(asrc[i] + k0), (lds_vp)(base + (wave * ASEG + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BSEG; ++i)
             __builtin_amdgcn_global_load_lds((gl_vp)(bsrc[i] + k0), (lds_vp)(base + A_BYTES + (wave * BSEG + i) * 1024), 16, 0, 0);
@@ -243,14 +244,19 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     // latency is hidden per tile).  R == 3: two tiles stay in flight across the barrier — counted s_waitcnt vmcnt(N) + raw
     // s_barrier (guide "Pipelining across barriers"): with K = 192 (3 tiles) the whole panel is requested up front and the
     // workgroup pays ONE DMA latency instead of three.
-    constexpr int DMA_PER_STAGE = 4 + BSEG;        // LDS-DMA instructions per wave and K-tile
+    constexpr int DMA_PER_STAGE = ASEG + BSEG;     // LDS-DMA instructions per wave and K-tile
+    static_assert(R != 3 || DMA_PER_STAGE == 6 || DMA_PER_STAGE == 8, "counted vmcnt immediates exist for 6 / 8 DMA per stage");
     const int nk = K / BKE;
-    stage(0, 0);
+    if (R != 1) stage(0, 0);
     if (R == 3 && nk > 1) stage(1, BKE);
     if (R == 2) __syncthreads();                   // vmcnt(0) + barrier: tile 0 landed for every wave
     for (int t = 0; t < nk; ++t) {
         int cur;
-        if (R == 2) {
+        if (R == 1) {                              // no ring: latency is hidden by co-resident workgroups only
+            cur = 0;
+            stage(0, t * BKE);
+            __syncthreads();
+        } else if (R == 2) {
             cur = t & 1;
             if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BKE);
         } else {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
         }
-        if (R == 2) __syncthreads();               // next tile landed (vmcnt(0)) and this one fully read
+        if (R == 2 || R == 1) __syncthreads();     // next tile landed (vmcnt(0)) and this one fully read
     }
     if (R == 3) __syncthreads();                   // all tiles consumed before the stages are reused by the epilogue
 
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
             for (int r = 0; r < 4; ++r) Cs[(wr * WM + a * 16 + 4 * g + r) * CSLD + wc * 64 + b * 16 + li] = acc[a][b][r];
     __syncthreads();
 
-    constexpr int CPR = BN / 8, RSTEP = 256 / CPR, ITERS = 128 / RSTEP;
+    constexpr int CPR = BN / 8, RSTEP = 256 / CPR, ITERS = BM / RSTEP;
     const int cchunk = tid % CPR, r0 = tid / CPR;
     const int col = n0 + cchunk * 8;
     const bool col_ok = col < N;
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     }
     if (epi.colsum_part) {
         // column sums of the compute-type output over this workgroup's rows -> part[blockIdx.y][N] (fixed order)
-        float* red = reinterpret_cast<float*>(smem) + 128 * CSLD;     // [RSTEP][BN]
+        float* red = reinterpret_cast<float*>(smem) + BM * CSLD;      // [RSTEP][BN]
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[r0 * BN + cchunk * 8 + j] = csum[j];
         __syncthreads();
@@ -659,19 +665,21 @@ __global__ void reduce_splits_grouped_kernel(TnGroup grp, const float* __restric
 
 }  // namespace
 
-static constexpr int glds_lds_bytes(int bn, int r = 2) {
-    const int stages = r * (128 * 128 + bn * 128), cs = 128 * (bn + 4) * 4 + (256 / (bn / 8)) * bn * 4;
+static constexpr int glds_lds_bytes(int bn, int r = 2, int bm = 128) {
+    const int stages = r * (bm * 128 + bn * 128), cs = bm * (bn + 4) * 4 + (256 / (bn / 8)) * bn * 4;
     return stages > cs ? stages : cs;
 }
+// row-tile height of the LDS-DMA NT GEMM for a problem: 64 rows while 128-row tiles would give fewer than ~4 workgroups per CU
+static int nt_tile_rows(int M, int N) { return ((long)cdiv(M, 128) * cdiv(N, 64) < 1024) ? 64 : 128; }
 static int g_gemm_inited = 0;
 int m3l_gemm_init() {
     if (g_gemm_inited) return 0;
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 3)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 3)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 128)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 64)));
+    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 64)));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
@@ -699,19 +707,20 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     const char* kind = (K % bke != 0) ? "gemm_nt_generic" : "gemm_nt_glds64";
     ProfScope prof(kind, M, N, K, 2.0 * M * N * K, st, bytes);
     if (K % bke == 0) {
-        static const bool wide = getenv("M3L_GEMM_BN128") != nullptr;      // A/B switch for the micro-benchmark
-        if (wide && (N % 128 == 0 || N >= 1024)) {
-            dim3 grid(8 * cdiv(N, 128) * cdiv(cdiv(M, 128), 8));
+        // 64-wide column tiles, 2-stage ring (48 KiB of LDS -> 3 workgroups per CU: measured faster than deeper rings or wider
+        // tiles at 1-2 workgroups per CU); 64-row tiles when 128-row tiles would leave the chip under-filled
+        if (nt_tile_rows(M, N) == 64) {
+            dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 64), 8));
             if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 128, 2><<<grid, 256, glds_lds_bytes(128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<bf16, 64, 2, 64><<<grid, 256, glds_lds_bytes(64, 2, 64), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
-                gemm_nt_glds_kernel<float, 128, 2><<<grid, 256, glds_lds_bytes(128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<float, 64, 2, 64><<<grid, 256, glds_lds_bytes(64, 2, 64), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
         } else {
             dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 128), 8));
             if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 64, 3><<<grid, 256, glds_lds_bytes(64, 3), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<bf16, 64, 2, 128><<<grid, 256, glds_lds_bytes(64, 2, 128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
             else
-                gemm_nt_glds_kernel<float, 64, 3><<<grid, 256, glds_lds_bytes(64, 3), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+                gemm_nt_glds_kernel<float, 64, 2, 128><<<grid, 256, glds_lds_bytes(64, 2, 128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
         }
     } else {
         M3L_CHECK(epi->colsum_part == nullptr, "gemm_nt: colsum epilogue needs K %% %d == 0", bke);
@@ -725,7 +734,7 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     return 0;
 }
 
-int m3l_gemm_nt_colsum_rows(int M) { return cdiv(M, 128); }
+int m3l_gemm_nt_colsum_rows(int M, int N) { return cdiv(M, nt_tile_rows(M, N)); }
 
 static int tn_splits(int M, int tiles) {
     int S = cdiv(512, tiles);                 // ~2 workgroups per CU over 256 CUs

@@ -32,7 +32,7 @@ struct GemmEpi {
     int ldc;
     float alpha;
     int n_bias;            // bias has n_bias valid entries (columns beyond read as 0); 0 -> N
-    float* colsum_part;    // [cdiv(M,128), N] per-row-block column sums of out_t (bias gradient fused into a dgrad) or null
+    float* colsum_part;    // [m3l_gemm_nt_colsum_rows(M, N), N] per-row-block column sums of out_t (bias gradient fused into a dgrad) or null
 };
 
 struct WeightDesc {
@@ -82,7 +82,7 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
                         hipStream_t st, const float* extra_part = nullptr, int extra_G = 0, int extra_width = 0,
                         float* extra_out = nullptr);
 int m3l_gemm_init();
-int m3l_gemm_nt_colsum_rows(int M);   // number of partial rows written through GemmEpi::colsum_part
+int m3l_gemm_nt_colsum_rows(int M, int N);   // number of partial rows written through GemmEpi::colsum_part
 
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,

@@ -197,7 +197,7 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     }
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
-    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M) * mlp);
+    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M, (int)mlp) * mlp);
     w.total = a.off + 256;
     return w;
 }
@@ -469,7 +469,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     if (side_init()) return 2;
     hipStream_t s2 = g_side.s;
     hipEvent_t wg_done[2] = {nullptr, nullptr};       // completion of the wgrad that last read buffer set i
-    const int csrows = m3l_gemm_nt_colsum_rows(M);
+    const int csrows = m3l_gemm_nt_colsum_rows(M, mlp);
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         TfLayer& L = w.L[l];
         const int cur = l & 1;

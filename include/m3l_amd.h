@@ -48,6 +48,8 @@ typedef struct m3l_tf_cfg {
 
 int m3l_version(void);
 int m3l_last_error(char* buf, size_t n);
+/* experimental: run the LayerNorms inside the epilogue of the neighbouring GEMM (returns the previous setting; default off) */
+int m3l_set_rowln(int enable);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.

@@ -829,6 +829,13 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
     return 0;
 }
 
+int m3l_reduce_rows_seg3(const float* part, int G, int D, float* out0, float* out1, float* out2, int accumulate, hipStream_t st) {
+    ReduceSegs segs = {{out0, out1, out2, nullptr}};
+    reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 3), 1024, 0, st>>>(part, G, 3 * D, D, segs, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
 int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st) {
     M3L_CHECK(M > 0 && N > 0, "colsum: bad shape");
     int G = cdiv(M, 64);

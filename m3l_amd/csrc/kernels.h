@@ -58,6 +58,26 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);
 int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws, size_t ws_bytes,
                 float* out, int ldo, int nvalid, int kvalid, int accumulate, hipStream_t st);
+// NT GEMM with the LayerNorm forward / backward fused on the full output row (gemm_rowln.hip); N must be 64*{1,2,3,4,6}
+enum { ROWLN_FWD = 0, ROWLN_BWD = 1 };
+struct RowLnEpi {
+    const float* bias;     // FWD: Linear bias [N] or null
+    const float* res;      // FWD: fp32 residual added before the norm; BWD: fp32 residual gradient added after it (may alias x_out)
+    const float* x;        // BWD: the LayerNorm input of the forward pass (fp32 [M, N])
+    const float* gamma;    // LayerNorm weight
+    const float* beta;     // FWD: LayerNorm bias
+    float* x_out;          // FWD: pre-norm sum (new residual stream); BWD: dx (fp32) — or null
+    void* out_t;           // FWD: normalised row in the compute type; BWD: dx in the compute type — or null
+    float* out_f32;        // FWD: normalised row in fp32 — or null
+    float* part;           // BWD: [cdiv(M,64)][3*N] partials: dgamma | dbeta | colsum(dx)
+    float eps;
+};
+bool m3l_gemm_nt_rowln_supported(int dtype, int N, int K);
+int m3l_gemm_nt_rowln(int dtype, int mode, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const RowLnEpi* ep,
+                      hipStream_t st);
+// out_i[j] = sum_g part[g*3*D + i*D + j], i = 0..2 (null outputs skipped): reduction of the LayerNorm-backward partial slabs
+int m3l_reduce_rows_seg3(const float* part, int G, int D, float* out0, float* out1, float* out2, int accumulate, hipStream_t st);
+
 // grouped weight-gradient GEMMs: up to 4 problems dW_i[N_i,K_i] = Y_i^T X_i that share M (one launch + one reduce)
 struct TnProblem {
     const void* Y;

@@ -4,6 +4,7 @@
 // the caller's HIP stream.  No allocation, no synchronisation, no host<->device copies: safe to capture in a hipGraph.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -64,6 +65,14 @@ struct Arena {
 };
 
 inline int pad8(int x) { return (x + 7) & ~7; }
+// LayerNorm forward / backward fused into the epilogue of the neighbouring GEMM (gemm_rowln.hip).  Correct (parity-tested) but
+// measured 2-3 % SLOWER than the separate kernels at cfg 2 on MI355X (a full-row tile caps the kernel at 2 workgroups per CU,
+// the stand-alone LayerNorm kernels run at 8 waves per SIMD), so it is off unless requested (M3L_ROWLN=1 / m3l_set_rowln).
+int g_rowln = -1;
+inline bool use_rowln() {
+    if (g_rowln < 0) g_rowln = getenv("M3L_ROWLN") != nullptr ? 1 : 0;
+    return g_rowln == 1;
+}
 inline size_t esz(int dtype) { return dtype ? 2 : 4; }
 
 // scratch big enough for every reduction / split-K slab of one module
@@ -218,6 +227,12 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
 extern "C" {
 
 int m3l_version(void) { return 100; }
+
+int m3l_set_rowln(int enable) {
+    const int old = use_rowln() ? 1 : 0;
+    g_rowln = enable ? 1 : 0;
+    return old;
+}
 
 int m3l_last_error(char* buf, size_t n) {
     if (buf && n) {
@@ -405,6 +420,11 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         prep_done = side_event();
         M3L_HIP(hipEventRecord(prep_done, g_side.s));
     }
+    // LayerNorms fused into the epilogue of the GEMM that produces their input (gemm_rowln.hip) when the row width allows it:
+    // out-proj + LN2 of the layer, fc2 + LN1 of the next layer (or the final norm).  Only the very first LN1 is a kernel.
+    const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, HD) && m3l_gemm_nt_rowln_supported(dt, D, mlp);
+    const void* const* tfin = tensors + 11 * c->depth;
+    bool final_done = false;
     for (int l = 0; l < c->depth; ++l) {
         TfLayer& L = w.L[l];
         const void* const* t = tensors + 11 * l;
@@ -412,29 +432,55 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
                     *ln2_b = (const float*)t[6], *fc1_b = (const float*)t[8], *fc2_b = (const float*)t[10];
         if (l == 1 && prep_done) M3L_HIP(hipStreamWaitEvent(st, prep_done, 0));
 
-        if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
+        if (!fuse || l == 0) {
+            if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
+        }
         GemmEpi e = epi0(3 * HD);
         e.out_t = L.qkv;
         if (m3l_gemm_nt(dt, L.xn1, D, L.wqkv, D, M, 3 * HD, D, &e, st)) return 1;
         if (m3l_attn_fwd(dt, L.qkv, L.o, L.lse, B, n, c->heads, st)) return 1;
-        if (c->project_out) {
-            e = epi0(D);
-            e.bias = out_b; e.res = x; e.out_f32 = L.x1;
-            if (m3l_gemm_nt(dt, L.o, HD, L.wo, HD, M, D, HD, &e, st)) return 1;
+        if (c->project_out && fuse) {
+            RowLnEpi r;
+            memset(&r, 0, sizeof(r));
+            r.bias = out_b; r.res = x; r.x_out = L.x1; r.gamma = ln2_w; r.beta = ln2_b; r.out_t = L.xn2; r.eps = LN_EPS;
+            if (m3l_gemm_nt_rowln(dt, ROWLN_FWD, L.o, HD, L.wo, HD, M, D, HD, &r, st)) return 1;
         } else {
-            if (m3l_axpy_t(dt, x, L.o, (long)M * D, L.x1, st)) return 1;
+            if (c->project_out) {
+                e = epi0(D);
+                e.bias = out_b; e.res = x; e.out_f32 = L.x1;
+                if (m3l_gemm_nt(dt, L.o, HD, L.wo, HD, M, D, HD, &e, st)) return 1;
+            } else {
+                if (m3l_axpy_t(dt, x, L.o, (long)M * D, L.x1, st)) return 1;
+            }
+            if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
         }
-        if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
         e = epi0(mlp);
         e.bias = fc1_b; e.act = 1; e.out_pre = L.u; e.out_t = L.h;
         if (m3l_gemm_nt(dt, L.xn2, D, L.w1, D, M, mlp, D, &e, st)) return 1;
-        e = epi0(D);
-        e.bias = fc2_b; e.res = L.x1; e.out_f32 = L.xout;
-        if (m3l_gemm_nt(dt, L.h, mlp, L.w2, mlp, M, D, mlp, &e, st)) return 1;
+        if (fuse) {
+            RowLnEpi r;
+            memset(&r, 0, sizeof(r));
+            r.bias = fc2_b; r.res = L.x1; r.x_out = L.xout; r.eps = LN_EPS;
+            if (l + 1 < c->depth) {
+                const void* const* tn = tensors + 11 * (l + 1);
+                r.gamma = (const float*)tn[0]; r.beta = (const float*)tn[1]; r.out_t = w.L[l + 1].xn1;
+            } else {
+                r.gamma = (const float*)tfin[0]; r.beta = (const float*)tfin[1];
+                r.out_t = dt ? y_t : (y_t ? y_t : nullptr);
+                r.out_f32 = y32;
+                if (dt == 0 && y_t && y32 == nullptr) { r.out_f32 = (float*)y_t; r.out_t = nullptr; }
+                final_done = true;
+            }
+            if (m3l_gemm_nt_rowln(dt, ROWLN_FWD, L.h, mlp, L.w2, mlp, M, D, mlp, &r, st)) return 1;
+        } else {
+            e = epi0(D);
+            e.bias = fc2_b; e.res = L.x1; e.out_f32 = L.xout;
+            if (m3l_gemm_nt(dt, L.h, mlp, L.w2, mlp, M, D, mlp, &e, st)) return 1;
+        }
         x = L.xout;
     }
-    const void* const* tf = tensors + 11 * c->depth;
-    return m3l_ln_fwd(dt, x, M, D, (const float*)tf[0], (const float*)tf[1], LN_EPS, y_t, y32, st);
+    if (final_done) return 0;
+    return m3l_ln_fwd(dt, x, M, D, (const float*)tfin[0], (const float*)tfin[1], LN_EPS, y_t, y32, st);
 }
 
 int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws, const void* dy,
@@ -467,6 +513,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             return 1;
     }
     if (side_init()) return 2;
+    const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, mlp) && m3l_gemm_nt_rowln_supported(dt, D, 3 * HD);
     hipStream_t s2 = g_side.s;
     hipEvent_t wg_done[2] = {nullptr, nullptr};       // completion of the wgrad that last read buffer set i
     const int csrows = m3l_gemm_nt_colsum_rows(M, mlp);
@@ -483,13 +530,22 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2[cur];
         if (m3l_gemm_nt(dt, w.dx_t[cur], D, L.w2T, D, M, mlp, D, &e, st)) return 1;                   // du = (dx W2) * gelu'(u)
         // (the per-row-block column sums in scratch2[cur] = fc1 bias gradient partials are reduced by the wgrad group's reduce)
-        e = epi0(D);
-        e.out_t = w.dxn;
-        if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;                 // dxn2 = du W1
-        // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
-        if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt, w.scratch, g[5], g[6],
-                       c->project_out ? g[4] : nullptr, 0, st))
-            return 1;
+        if (fuse) {
+            // dxn2 = du W1 and the LN2 backward in one kernel: dx1 = dx + dLN(dxn2) (in place) + compute-type copy + partials
+            RowLnEpi r;
+            memset(&r, 0, sizeof(r));
+            r.x = L.x1; r.gamma = (const float*)t[5]; r.res = w.dx; r.x_out = w.dx; r.out_t = w.dx1_t[cur]; r.part = w.scratch; r.eps = LN_EPS;
+            if (m3l_gemm_nt_rowln(dt, ROWLN_BWD, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &r, st)) return 1;
+            if (m3l_reduce_rows_seg3(w.scratch, cdiv(M, 64), D, g[5], g[6], c->project_out ? g[4] : nullptr, 0, st)) return 1;
+        } else {
+            e = epi0(D);
+            e.out_t = w.dxn;
+            if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;             // dxn2 = du W1
+            // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
+            if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt, w.scratch, g[5], g[6],
+                           c->project_out ? g[4] : nullptr, 0, st))
+                return 1;
+        }
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
         const void* d_o = w.dx1_t[cur];
         if (c->project_out) {
@@ -516,17 +572,27 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             wg_done[cur] = side_event();
             M3L_HIP(hipEventRecord(wg_done[cur], s2));
         }
-        e = epi0(D);
-        e.out_t = w.dxn;
-        if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
         // the last kernel of this layer writes dx_t[cur^1] (and the next layer then du/dx1_t/dqkv[cur^1]): the wgrad of layer
         // l+1, which reads that set, must be done
-        if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
         float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
         float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
-        if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt, w.scratch, g[0], g[1],
-                       db_prev, 0, st))
-            return 1;
+        if (fuse) {
+            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
+            RowLnEpi r;
+            memset(&r, 0, sizeof(r));
+            r.x = xl; r.gamma = (const float*)t[0]; r.res = w.dx; r.x_out = dx_dst; r.out_t = l ? w.dx_t[cur ^ 1] : nullptr;
+            r.part = w.scratch; r.eps = LN_EPS;
+            if (m3l_gemm_nt_rowln(dt, ROWLN_BWD, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &r, st)) return 1;   // dxn1 + LN1 backward
+            if (m3l_reduce_rows_seg3(w.scratch, cdiv(M, 64), D, g[0], g[1], db_prev, 0, st)) return 1;
+        } else {
+            e = epi0(D);
+            e.out_t = w.dxn;
+            if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
+            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
+            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt, w.scratch, g[0], g[1],
+                           db_prev, 0, st))
+                return 1;
+        }
     }
     // join: every weight gradient is complete before anything later on the caller's stream
     for (int i = 0; i < 2; ++i)

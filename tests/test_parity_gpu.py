@@ -402,3 +402,34 @@ def test_chunked_transformer_backward_is_bit_identical(chunk):
     for n, p in mae.named_parameters():
         if n in ref:
             assert torch.equal(p.grad, ref[n]), n
+
+
+def test_fused_gemm_layernorm_path_matches_separate_kernels():
+    """gemm_rowln.hip (LayerNorm forward / backward inside the GEMM epilogue; experimental, off by default) must reproduce the
+    separate-kernel path: same loss to 1e-5 and every gradient to 2e-3 (fp32), and the bf16 loss within 1e-2 of the oracle."""
+    from m3l_amd import _lib as L
+    torch.manual_seed(31)
+    enc = VTT(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=192, depth=2, heads=3, mlp_dim=768)
+    mae = VTMAE(encoder=enc, decoder_dim=192, decoder_depth=2, decoder_heads=3).to(DEV)
+    B = 5
+    x = {"image": torch.rand(B, 3, 64, 64, device=DEV), "tactile1": torch.rand(B, 3, 32, 32, device=DEV),
+         "tactile2": torch.rand(B, 3, 32, 32, device=DEV)}
+    noises = [torch.rand(B, 64, device=DEV) for _ in range(3)]
+    loss0 = mae(x, mask_noise=noises)
+    loss0.backward()
+    ref = {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}
+    mae.zero_grad(set_to_none=True)
+    old = L.lib().m3l_set_rowln(1)
+    try:
+        loss1 = mae(x, mask_noise=noises)
+        loss1.backward()
+        assert abs(float(loss1.detach()) - float(loss0.detach())) <= 1e-5 * abs(float(loss0.detach()))
+        for n, p in mae.named_parameters():
+            if n in ref:
+                err = float((p.grad - ref[n]).abs().max()) / max(1e-7, float(ref[n].abs().max()))
+                assert err <= 2e-3, (n, err)
+        mae.set_compute_dtype("bf16")
+        lb = mae(x, mask_noise=noises)
+        assert abs(float(lb.detach()) - float(loss0.detach())) <= 1e-2 * abs(float(loss0.detach()))
+    finally:
+        L.lib().m3l_set_rowln(old)

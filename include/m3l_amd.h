@@ -58,6 +58,10 @@ int m3l_mask_counts(const m3l_geom* g, double ratio, int* counts_host);
 int m3l_mask_sample(const m3l_geom* g, double ratio, int B, const float* const* noise, int64_t* masked, int64_t* unmasked,
                     void* stream);
 
+/* explicit per-modality masked counts (VTMAE.reconstruct: int(r*n_img), int(r*n_tac_total/k); pretrain_models.py:425,433) */
+int m3l_mask_sample_counts(const m3l_geom* g, int nm_img, int nm_tac, int B, const float* const* noise, int64_t* masked,
+                           int64_t* unmasked, void* stream);
+
 /* ---- patch embed.  idx == NULL: all patches (get_embeddings); else idx = unmasked (B, L) and only those rows are embedded.
  * cnt_img = number of image entries at the head of each list row (n_img when idx == NULL, n_img - nm_img for the visible list).
  * tensors: image {ln1_w, ln1_b, W[D,pd], b, ln2_w, ln2_b}, tactile {same 6}, mod_emb[(1+k),D], pos_img[n_img,D], pos_tac[k*n_tac,D]
@@ -101,6 +105,10 @@ size_t m3l_heads_ws_bytes(const m3l_geom* g, int dd, int dtype, int B, int nmask
 int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
                        const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
                        float* loss, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream);
+/* the same + loss_parts (f32[2], may be NULL): mse(image) and 10*mse(tactile) separately (VTMAE.reconstruct logging) */
+int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                        const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
+                        float* loss, float* loss_parts, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream);
 /* d_dec out: compute type (B, N, dd), zero on visible rows.  dloss: device f32 scalar (upstream gradient) or NULL for 1. */
 int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
                        const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream);

@@ -33,6 +33,7 @@ _SIGS = {
     "m3l_set_rowln": (c_i, [c_i]),
     "m3l_mask_counts": (c_i, [C.POINTER(Geom), C.c_double, C.POINTER(c_i)]),
     "m3l_mask_sample": (c_i, [C.POINTER(Geom), C.c_double, c_i, c_p, c_p, c_p, c_p]),
+    "m3l_mask_sample_counts": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "m3l_embed_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i]),
     "m3l_embed_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_embed_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -47,6 +48,8 @@ _SIGS = {
     "m3l_heads_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i]),
     "m3l_heads_loss_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                  c_p, c_p, c_p]),
+    "m3l_heads_loss_fwd2": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                  c_p, c_p, c_p, c_p]),
     "m3l_heads_loss_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
     "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

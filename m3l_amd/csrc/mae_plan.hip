@@ -253,11 +253,20 @@ int m3l_mask_sample(const m3l_geom* g, double ratio, int B, const float* const* 
                     void* stream) {
     if (check_geom(g)) return 1;
     M3L_CHECK(ratio > 0.0 && ratio < 1.0, "masking ratio must be kept between 0 and 1");
+    int c[6];
+    mask_counts(geo_of(g), ratio, c);
+    return m3l_mask_sample_counts(g, c[2], c[3], B, noise, masked, unmasked, stream);
+}
+
+// the same with explicit per-modality masked counts (VTMAE.reconstruct uses its own rule: int(r*n_img), int(r*n_tac_total/k),
+// pretrain_models.py:425,433)
+int m3l_mask_sample_counts(const m3l_geom* g, int nm_img, int nm_tac, int B, const float* const* noise, int64_t* masked,
+                           int64_t* unmasked, void* stream) {
+    if (check_geom(g)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const Geo ge = geo_of(g);
-    int c[6];
-    mask_counts(ge, ratio, c);
-    const int nmask = c[0], nvis = c[1], nm_img = c[2], nm_tac = c[3];
+    M3L_CHECK(nm_img >= 0 && nm_img <= ge.n_img && nm_tac >= 0 && nm_tac <= ge.n_tac, "mask_sample: bad counts %d %d", nm_img, nm_tac);
+    const int nmask = nm_img + ge.k * nm_tac, nvis = ge.n_img + ge.k * ge.n_tac - nmask;
     int ni = 0;
     if (ge.n_img > 0) {
         if (m3l_mask_rank(noise[ni++], B, ge.n_img, nm_img, 0, masked, nmask, 0, unmasked, nvis, 0, st)) return 1;
@@ -733,6 +742,14 @@ size_t m3l_heads_ws_bytes(const m3l_geom* g, int dd, int dtype, int B, int nmask
 int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
                        const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
                        float* loss, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream) {
+    return m3l_heads_loss_fwd2(g, dd, dtype, B, N, nmask, nm_img, masked, image, tactiles, dec_t, tensors, ws, loss, nullptr, pred_img,
+                               tgt_img, pred_tac, tgt_tac, stream);
+}
+
+// loss_parts (optional, f32[2]): the two WEIGHTED terms of the loss separately: mse(image), 10 * mse(tactile)
+int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
+                        const float* image, const float* const* tactiles, const void* dec_t, const void* const* tensors, void* ws,
+                        float* loss, float* loss_parts, float* pred_img, float* tgt_img, float* pred_tac, float* tgt_tac, void* stream) {
     if (check_geom(g)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const Geo ge = geo_of(g);
@@ -744,6 +761,7 @@ int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
     float* tgt[2] = {tgt_img, tgt_tac};
     float* pred_out[2] = {pred_img, pred_tac};
     int nparts = 0;
+    int part_beg[2] = {0, 0}, part_cnt[2] = {0, 0};
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
@@ -764,10 +782,16 @@ int m3l_heads_loss_fwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
         if (m3l_mse(dtype, w.g[i].pred, pdp[i], &pgs[i], masked, nmask, j0[i], cnt[i], B, weight[i], w.loss_part + nparts, &nb,
                     w.g[i].dpred, tgt[i], st))
             return 1;
+        part_beg[i] = nparts; part_cnt[i] = nb;
         nparts += nb;
         if (pred_out[i])
             M3L_HIP(hipMemcpy2DAsync(pred_out[i], (size_t)pd[i] * 4, w.g[i].pred, (size_t)pdp[i] * 4, (size_t)pd[i] * 4, rows,
                                      hipMemcpyDeviceToDevice, st));
+    }
+    if (loss_parts) {
+        M3L_HIP(hipMemsetAsync(loss_parts, 0, 2 * sizeof(float), st));
+        for (int i = 0; i < 2; ++i)
+            if (part_cnt[i] && m3l_reduce_rows(w.loss_part + part_beg[i], part_cnt[i], 1, 1, loss_parts + i, 0, st)) return 1;
     }
     return m3l_reduce_rows(w.loss_part, nparts, 1, 1, loss, 0, st);
 }

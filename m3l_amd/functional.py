@@ -61,9 +61,14 @@ def mask_counts(geom: L.Geom, ratio: float):
     return dict(num_masked=out[0], num_unmasked=out[1], nm_img=out[2], nm_tac=out[3], n_img=out[4], n_tac=out[5])
 
 
-def mask_sample(geom: L.Geom, ratio: float, noises):
-    """noises: list of (B, n_i) f32 CUDA tensors in the reference's RNG order.  Returns int64 (masked, unmasked)."""
+def mask_sample(geom: L.Geom, ratio: float, noises, counts=None):
+    """noises: list of (B, n_i) f32 CUDA tensors in the reference's RNG order.  Returns int64 (masked, unmasked).
+    counts = (nm_img, nm_tac) overrides the forward's integer rule (VTMAE.reconstruct has its own)."""
     c = mask_counts(geom, ratio)
+    if counts is not None:
+        k = geom.num_tactiles if geom.use_tactile else 0
+        c = dict(c, nm_img=counts[0], nm_tac=counts[1], num_masked=counts[0] + k * counts[1])
+        c["num_unmasked"] = c["n_img"] + k * c["n_tac"] - c["num_masked"]
     B = noises[0].shape[0]
     dev = noises[0].device
     noises = [_f32c(n) for n in noises]
@@ -71,8 +76,8 @@ def mask_sample(geom: L.Geom, ratio: float, noises):
         _require_cuda(n, "mask noise")
     masked = torch.empty(B, c["num_masked"], dtype=torch.int64, device=dev)
     unmasked = torch.empty(B, c["num_unmasked"], dtype=torch.int64, device=dev)
-    L.check(L.lib().m3l_mask_sample(C.byref(geom), float(ratio), B, L.ptr_array(noises), L.ptr(masked), L.ptr(unmasked),
-                                    _stream()), "m3l_mask_sample")
+    L.check(L.lib().m3l_mask_sample_counts(C.byref(geom), c["nm_img"], c["nm_tac"], B, L.ptr_array(noises), L.ptr(masked),
+                                           L.ptr(unmasked), _stream()), "m3l_mask_sample")
     return masked, unmasked, c
 
 
@@ -253,9 +258,13 @@ class HeadsLossFn(torch.autograd.Function):
             outs = [torch.zeros(B, nm_img, pd_i, device=dev), torch.zeros(B, nm_img, pd_i, device=dev),
                     torch.zeros(B, n_t, pd_t, device=dev), torch.zeros(B, n_t, pd_t, device=dev)]
             dump.update(pred_pixel=outs[0], target_pixel=outs[1], pred_tactile=outs[2], target_tactile=outs[3])
-        L.check(L.lib().m3l_heads_loss_fwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr(image),
-                                           L.ptr_array(tactiles), L.ptr(dec_t), L.ptr_array(tens), L.ptr(ws), L.ptr(loss),
-                                           L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), _stream()),
+        parts = None
+        if dump is not None:
+            parts = torch.zeros(2, dtype=torch.float32, device=dev)
+            dump["loss_parts"] = parts
+        L.check(L.lib().m3l_heads_loss_fwd2(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr(image),
+                                            L.ptr_array(tactiles), L.ptr(dec_t), L.ptr_array(tens), L.ptr(ws), L.ptr(loss), L.ptr(parts),
+                                            L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), _stream()),
                 "m3l_heads_loss_fwd")
         ctx.saved = (geom, dd, dt, masked, nm_img, tens, ws, (B, N), dec_t.dtype)
         ctx.used = [image is not None] * 2 + [len(tactiles) > 0] * 2

@@ -287,8 +287,7 @@ class VTMAE(nn.Module):
                                 *self._embed_tensors())
 
     # ------------------------------------------------------------------------------------------------------------
-    def forward(self, x, use_vision=True, use_tactile=True, mask_noise=None, dump=None):
-        """Reconstruction loss (0-dim tensor with grad), pretrain_models.py:146-342."""
+    def _step(self, x, use_vision, use_tactile, mask_noise, dump, counts=None):
         image, tactiles, geom, ref = self._inputs(x, use_vision, use_tactile)
         B, dev = ref.shape[0], ref.device
         dt = Fn.dtype_code(self.compute_dtype)
@@ -297,7 +296,7 @@ class VTMAE(nn.Module):
         if mask_noise is None:
             mask_noise = [torch.rand(B, n, device=dev) for n in sizes]          # reference RNG order (:229,:237)
         assert [tuple(n.shape) for n in mask_noise] == [(B, n) for n in sizes], "mask_noise: one (B, n) tensor per modality"
-        masked, unmasked, _ = Fn.mask_sample(geom, self.masking_ratio, [n.to(dev) for n in mask_noise])
+        masked, unmasked, c = Fn.mask_sample(geom, self.masking_ratio, [n.to(dev) for n in mask_noise], counts)
         self.last_mask = (masked, unmasked)
         nvis_img = c["n_img"] - c["nm_img"]
 
@@ -317,8 +316,71 @@ class VTMAE(nn.Module):
                                         dump, dec_t, *self._head_tensors())
         if dump is not None:
             dump.update(masked_indices=masked, unmasked_indices=unmasked, encoder_in=tokens.detach(), encoder_out=enc32.detach(),
-                        decoder_in=dec_in.detach(), decoder_out=dec_t.detach())
+                        decoder_in=dec_in.detach(), decoder_out=dec_t.detach(), counts=c)
         return loss
+
+    def forward(self, x, use_vision=True, use_tactile=True, mask_noise=None, dump=None):
+        """Reconstruction loss (0-dim tensor with grad), pretrain_models.py:146-342."""
+        return self._step(x, use_vision, use_tactile, mask_noise, dump)
+
+    @torch.no_grad()
+    def reconstruct(self, x, mask_ratio=None, use_vision=True, use_tactile=True, mask_noise=None):
+        """Visual-logging companion of forward (pretrain_models.py:344-586): masks with its OWN count rule
+        (int(r * n_img) image patches, int(r * n_tac_total / k) per sensor), runs the auto-encoder and returns
+        {'image_rec', 'image_masked', 'recon_loss_image', 'tactile_rec', 'tactile_masked', 'recon_loss_tactile'}:
+        frames with the masked patches replaced by the prediction / by 0.5 (image) or inf (tactile).  The arithmetic is
+        the same HIP step as forward; torch only re-tiles patches into frames."""
+        r = self.masking_ratio if mask_ratio is None else mask_ratio
+        image, tactiles, geom, ref = self._inputs(x, use_vision, use_tactile)
+        c0 = Fn.mask_counts(geom, self.masking_ratio)
+        k = len(tactiles)
+        nm_img = int(r * c0["n_img"]) if image is not None else 0
+        nm_tac = int(r * (k * c0["n_tac"]) / k) if k else 0
+        keep, self.masking_ratio = self.masking_ratio, r
+        try:
+            dump = {}
+            self._step(x, use_vision, use_tactile, mask_noise, dump, counts=(nm_img, nm_tac))
+        finally:
+            self.masking_ratio = keep
+        B = ref.shape[0]
+        br = torch.arange(B, device=ref.device)[:, None]
+        masked = dump["masked_indices"]
+        n_img = c0["n_img"] if image is not None else 0
+        mi_img, mi_tac = masked[:, :nm_img], masked[:, nm_img:] - n_img
+        enc = self.encoder
+        out = {}
+
+        def frames(p, n, gh, gw, ph, pw):     # 'b (n h w) (p1 p2 c) -> b (n c) (h p1) (w p2)'
+            b, _, pd = p.shape
+            ch = pd // (ph * pw)
+            return p.reshape(b, n, gh, gw, ph, pw, ch).permute(0, 1, 6, 2, 4, 3, 5).reshape(b, n * ch, gh * ph, gw * pw)
+        if image is not None:
+            gh, gw = enc.image_height // enc.image_patch_height, enc.image_width // enc.image_patch_width
+            patches = self.image_to_patch(image.float())
+            vis = patches.clone()
+            vis[br, mi_img] = 0.5
+            if self.early_conv_masking:
+                rec = dump["pred_pixel"]
+            else:
+                rec = patches.clone()
+                rec[br, mi_img] = dump["pred_pixel"]
+            out["image_rec"] = frames(rec, 1, gh, gw, enc.image_patch_height, enc.image_patch_width)
+            out["image_masked"] = frames(vis, 1, gh, gw, enc.image_patch_height, enc.image_patch_width)
+            out["recon_loss_image"] = dump["loss_parts"][0]
+        if k:
+            gh, gw = enc.tactile_height // enc.tactile_patch_height, enc.tactile_width // enc.tactile_patch_width
+            patches = torch.cat([self.tactile_to_patch(t.float()) for t in tactiles], dim=1)
+            vis = patches.clone()
+            vis[br, mi_tac] = float("inf")
+            if self.early_conv_masking:
+                rec = dump["pred_tactile"]
+            else:
+                rec = patches.clone()
+                rec[br, mi_tac] = dump["pred_tactile"]
+            out["tactile_rec"] = frames(rec, k, gh, gw, enc.tactile_patch_height, enc.tactile_patch_width)
+            out["tactile_masked"] = frames(vis, k, gh, gw, enc.tactile_patch_height, enc.tactile_patch_width)
+            out["recon_loss_tactile"] = dump["loss_parts"][1] / 10.0
+        return out
 
     def get_embeddings(self, x, eval=True, use_vision=True, use_tactile=True):
         """Encoder over ALL tokens, no masking (pretrain_models.py:588-668) -> (B, N, D) f32 with grad."""
@@ -335,3 +397,34 @@ class VTMAE(nn.Module):
     def initialize_training(self, train_args):
         self.optimizer = optim.AdamW(self.parameters(), lr=train_args['lr'])
         self.batch_size = train_args['batch_size']
+
+    def train_iterations(self, iterations, replay_buffer, no_tactile=False):
+        """Stand-alone MAE training from a replay buffer (pretrain_models.py:679-715): `iterations` steps of
+        sample batch -> stack frames -> vt_load -> loss -> backward -> clip_grad_norm_(0.5) -> AdamW step; leaves the module in
+        eval mode.  replay_buffer: list of {'image': (fs, H, W, 3), 'tactile': (fs, 6, h, w)} dicts."""
+        import random
+        import numpy as np
+        from .pretrain_utils import vt_load
+        if len(replay_buffer) < self.batch_size:
+            print("Not enough samples in replay buffer")
+            return
+        self.train()
+        dev = self.mask_token.device
+        for _ in range(iterations):
+            batch = random.choices(replay_buffer, k=self.batch_size)
+            obs = {}
+            for key in (['image'] if no_tactile else ['image', 'tactile']):
+                obs[key] = np.stack([b[key] for b in batch])
+            if 'image' in obs:                                  # (B, fs, H, W, 3) -> (B, H, W, 3*fs)
+                im = obs['image'].transpose((0, 2, 3, 1, 4))
+                obs['image'] = im.reshape((im.shape[0], im.shape[1], im.shape[2], -1))
+            if 'tactile' in obs:                                # (B, fs, 6, h, w) -> (B, 6*fs, h, w)
+                t = obs['tactile']
+                obs['tactile'] = t.reshape((t.shape[0], -1, t.shape[3], t.shape[4]))
+            xb = vt_load(obs, frame_stack=self.frame_stack, device=dev)
+            self.optimizer.zero_grad()
+            r_loss = self(xb, use_tactile=not no_tactile)
+            r_loss.backward()
+            torch.nn.utils.clip_grad_norm_(self.parameters(), 0.5)
+            self.optimizer.step()
+        self.eval()

@@ -90,7 +90,7 @@ def stable_argsort_rows(noise: np.ndarray) -> np.ndarray:
     return np.argsort(noise, axis=-1, kind="stable").astype(np.int64)
 
 
-def mask_indices(noises: List[np.ndarray], ratio: float, n_img: int, n_tac: int, num_tactiles: int, perms=None):
+def mask_indices(noises: List[np.ndarray], ratio: float, n_img: int, n_tac: int, num_tactiles: int, perms=None, counts=None):
     """pretrain_models.py:229-248.  noises = [image (B,n_img), tactile_1 (B,n_tac), ...] in RNG order.
     Returns (masked_indices, unmasked_indices, nm_img, nm_tac) as int64 (B, *).
 
@@ -99,6 +99,8 @@ def mask_indices(noises: List[np.ndarray], ratio: float, n_img: int, n_tac: int,
     (observed here on 64-wide rows, and its CUDA kernel differs again), i.e. the reference's own order of tied
     keys is unspecified.  `perms` lets a test inject the permutations a particular reference run produced."""
     _, nm_img, nm_tac = mask_counts(ratio, n_img, n_tac * num_tactiles, num_tactiles)
+    if counts is not None:          # reconstruct() has its own count rule (pretrain_models.py:425,433)
+        nm_img, nm_tac = counts
     perm = stable_argsort_rows(noises[0]) if perms is None else np.asarray(perms[0], dtype=np.int64)
     masked = [perm[:, :nm_img]]
     unmasked = [perm[:, nm_img:]]
@@ -224,14 +226,14 @@ def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=Tru
 
 
 def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch.Tensor],
-                  noises: List[torch.Tensor], use_vision=True, use_tactile=True, perms=None) -> Dict[str, torch.Tensor]:
+                  noises: List[torch.Tensor], use_vision=True, use_tactile=True, perms=None, counts=None) -> Dict[str, torch.Tensor]:
     """VTMAE.forward (pretrain_models.py:146-342), early_conv_masking=False, use_sincosmod_encodings=True.
     Returns every intermediate the fixtures record plus 'loss'."""
     nt = cfg.num_tactiles if use_tactile else 0
     n_img = cfg.n_img if use_vision else 0
     tokens, img_patches, tac_patches = encoder_tokens(P, cfg, x, use_vision, use_tactile)
     B = tokens.shape[0]
-    masked, unmasked, nm_img, nm_tac = mask_indices([np.asarray(z) for z in noises], cfg.ratio, n_img, cfg.n_tac, nt, perms)
+    masked, unmasked, nm_img, nm_tac = mask_indices([np.asarray(z) for z in noises], cfg.ratio, n_img, cfg.n_tac, nt, perms, counts)
     masked_t, unmasked_t = torch.from_numpy(masked), torch.from_numpy(unmasked)
     br = torch.arange(B)[:, None]
     vis = tokens[br, unmasked_t]
@@ -277,6 +279,46 @@ def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch
         out["pred_pixel"], out["target_pixel"] = pred_i, tgt_i
         loss = loss + F.mse_loss(pred_i, tgt_i)
     out["loss"] = loss
+    return out
+
+
+def _frames(p, n, gh, gw, ph, pw):
+    """'b (n h w) (p1 p2 c) -> b (n c) (h p1) (w p2)' (pretrain_models.py:464,476)."""
+    b, _, pd = p.shape
+    c = pd // (ph * pw)
+    return p.reshape(b, n, gh, gw, ph, pw, c).permute(0, 1, 6, 2, 4, 3, 5).reshape(b, n * c, gh * ph, gw * pw)
+
+
+def reconstruct(P, cfg: OracleCfg, x, noises, mask_ratio=None, use_vision=True, use_tactile=True):
+    """VTMAE.reconstruct (pretrain_models.py:344-586): masked counts int(r * n_img) / int(r * n_tac_total / k)
+    (:425,:433), frames with masked patches = prediction ('*_rec') or 0.5 / inf ('*_masked'), unweighted MSEs."""
+    r = cfg.ratio if mask_ratio is None else mask_ratio
+    nt = cfg.num_tactiles if use_tactile else 0
+    n_img = cfg.n_img if use_vision else 0
+    nm_img = int(r * n_img)
+    nm_tac = int(r * (nt * cfg.n_tac) / nt) if nt else 0
+    o = vtmae_forward(P, cfg, x, noises, use_vision, use_tactile, counts=(nm_img, nm_tac))
+    early = "early_conv_vision.conv1.weight" in P
+    B = o["masked_indices"].shape[0]
+    br = torch.arange(B)[:, None]
+    mi_img, mi_tac = o["masked_indices"][:, :nm_img], o["masked_indices"][:, nm_img:] - n_img
+    out = {}
+    if use_vision:
+        g, ph = cfg.image_hw // cfg.image_patch, cfg.image_patch
+        patches = patchify(x["image"], ph)
+        vis = patches.clone()
+        vis[br, mi_img] = 0.5
+        rec = o["pred_pixel"] if early else patches.index_put((br, mi_img), o["pred_pixel"])
+        out["image_rec"], out["image_masked"] = _frames(rec, 1, g, g, ph, ph), _frames(vis, 1, g, g, ph, ph)
+        out["recon_loss_image"] = F.mse_loss(o["pred_pixel"], o["target_pixel"])
+    if nt:
+        g, ph = cfg.tactile_hw // cfg.tactile_patch, cfg.tactile_patch
+        patches = torch.cat([patchify(x[f"tactile{i + 1}"], ph) for i in range(nt)], 1)
+        vis = patches.clone()
+        vis[br, mi_tac] = float("inf")
+        rec = o["pred_tactile"] if early else patches.index_put((br, mi_tac), o["pred_tactile"])
+        out["tactile_rec"], out["tactile_masked"] = _frames(rec, nt, g, g, ph, ph), _frames(vis, nt, g, g, ph, ph)
+        out["recon_loss_tactile"] = F.mse_loss(o["pred_tactile"], o["target_tactile"])
     return out
 
 

@@ -180,6 +180,40 @@ def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp
     print(f"{name}: loss={float(loss):.8f}  keys={len(out)}")
 
 
+def run_reconstruct(ref, name, *, early_conv, ratio, mask_ratio, seed, use_tactile=True):
+    """`VTMAE.reconstruct` (pretrain_models.py:344-586): its own mask-count rule and the logging frames."""
+    torch.manual_seed(seed)
+    B, C, nt = 2, 3, 2
+    enc = ref.VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2,
+                  mlp_dim=128, image_channels=C, tactile_channels=C, num_tactiles=nt)
+    mae = ref.VTMAE(encoder=enc, decoder_dim=64, masking_ratio=ratio, decoder_depth=1, decoder_heads=2, num_tactiles=nt,
+                    early_conv_masking=early_conv, use_sincosmod_encodings=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n_, p in mae.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    mae.eval()
+    x = {"image": torch.rand(B, C, 32, 32, generator=g)}
+    for i in range(nt):
+        x[f"tactile{i + 1}"] = torch.rand(B, C, 16, 16, generator=g)
+    noises = [_noise(g, B, 16)] + ([_noise(g, B, 16) for _ in range(nt)] if use_tactile else [])
+    with torch.no_grad(), _RandQueue(noises):
+        r = mae.reconstruct({k: v.clone() for k, v in x.items()}, mask_ratio=mask_ratio, use_tactile=use_tactile)
+    out = {"param/" + k: v.detach().numpy() for k, v in mae.state_dict().items()}
+    out.update({"input/" + k: v.numpy() for k, v in x.items()})
+    for i, nz in enumerate(noises):
+        out[f"noise/{i}"] = nz.numpy()
+    out.update({"out/" + k: v.detach().numpy() for k, v in r.items()})
+    out["meta"] = np.array([32, 16, 8, 4, 64, 1, 2, 128, C, nt, 64, 1, 2, B], dtype=np.int64)
+    out["ratio"] = np.array(ratio, dtype=np.float64)
+    out["mask_ratio"] = np.array(-1.0 if mask_ratio is None else mask_ratio, dtype=np.float64)
+    out["early_conv"] = np.array(int(early_conv))
+    out["use_tactile"] = np.array(int(use_tactile))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: keys={sorted(r.keys())} losses={[float(v) for k, v in r.items() if k.startswith('recon_loss')]}")
+
+
 def run_vt_load(ref):
     import utils.pretrain_utils as pu  # the reference's own file (cv2 / SB3 logger stubbed)
     g = np.random.default_rng(7)
@@ -240,6 +274,15 @@ def run_vtt_dino():
 
 def main():
     ref = _load_reference()
+    if "--reconstruct-only" not in sys.argv:
+        _main_cases(ref)
+    # F: reconstruct(): count rule int(r*n) (0.7*16 -> 11 image, 11 per sensor), both masking modes, default + vision-only
+    run_reconstruct(ref, "recon_small", early_conv=False, ratio=0.75, mask_ratio=0.7, seed=31)
+    run_reconstruct(ref, "recon_default_ratio", early_conv=False, ratio=0.8, mask_ratio=None, seed=32, use_tactile=False)
+    run_reconstruct(ref, "recon_earlyconv", early_conv=True, ratio=0.75, mask_ratio=0.5, seed=33)
+
+
+def _main_cases(ref):
     # A: vision + 2 tactile, the cfg-2 structure at reduced widths (D == dd -> enc_to_dec is Identity)
     run_case(ref, "vt_small", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=2, heads=2, mlp=128, C=3,
              num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=11, with_embeddings=True)

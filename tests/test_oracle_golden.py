@@ -156,3 +156,27 @@ def test_dino_style_vtt(golden_dir):
     np.testing.assert_allclose(full["x_prenorm"].numpy(), z["full/x_prenorm"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(full["x_norm_patchtokens"].numpy(), z["full/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(mk["x_norm_patchtokens"].numpy(), z["masked/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)
+
+
+RECON = ["recon_small", "recon_default_ratio", "recon_earlyconv"]
+
+
+@pytest.mark.parametrize("name", RECON)
+def test_reconstruct(golden_dir, name):
+    """VTMAE.reconstruct (pretrain_models.py:344-586): frames bit-for-position (0.5 / inf fills), predictions and MSEs."""
+    z = _load(golden_dir, name)
+    cfg = O.cfg_from_meta(z["meta"], z["ratio"])
+    P = O.load_fixture_params(z)
+    x, noises = _inputs(z)
+    mr = float(z["mask_ratio"])
+    with torch.no_grad():
+        r = O.reconstruct(P, cfg, x, noises, mask_ratio=None if mr < 0 else mr, use_tactile=bool(int(z["use_tactile"])))
+    want = sorted(k[4:] for k in z.files if k.startswith("out/"))
+    assert sorted(r.keys()) == want
+    for k in want:
+        a, b = r[k].numpy(), z["out/" + k]
+        assert a.shape == b.shape, k
+        if k.endswith("_masked"):
+            np.testing.assert_array_equal(a, b)               # raw pixels + fill values: exact
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5, err_msg=k)

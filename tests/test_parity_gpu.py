@@ -433,3 +433,61 @@ def test_fused_gemm_layernorm_path_matches_separate_kernels():
         assert abs(float(lb.detach()) - float(loss0.detach())) <= 1e-2 * abs(float(loss0.detach()))
     finally:
         L.lib().m3l_set_rowln(old)
+
+
+@pytest.mark.parametrize("name", ["recon_small", "recon_default_ratio", "recon_earlyconv"])
+def test_reconstruct_golden(golden_dir, name):
+    """VTMAE.reconstruct (pretrain_models.py:344-586) against the reference's own outputs: masked frames exact,
+    reconstructed frames / MSEs to fp32 tolerance, and the module's masking_ratio untouched afterwards."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    mae = build_from_fixture(z).eval()
+    x, noises = inputs_of(z)
+    mr = float(z["mask_ratio"])
+    keep = mae.masking_ratio
+    r = mae.reconstruct(x, mask_ratio=None if mr < 0 else mr, use_tactile=bool(int(z["use_tactile"])), mask_noise=noises)
+    assert mae.masking_ratio == keep
+    want = sorted(k[4:] for k in z.files if k.startswith("out/"))
+    assert sorted(r.keys()) == want
+    for k in want:
+        a, b = r[k].float().cpu().numpy(), z["out/" + k]
+        assert a.shape == b.shape, k
+        if k.endswith("_masked"):
+            np.testing.assert_array_equal(a, b)
+        elif k.startswith("recon_loss"):
+            assert abs(float(a) - float(b)) <= 1e-4 * abs(float(b)), k
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def test_train_iterations_replay_buffer():
+    """VTMAE.train_iterations (pretrain_models.py:679-715): too-small buffer is a no-op; otherwise `iterations` clipped
+    AdamW steps that change the weights, lower the loss on the buffer, and leave the module in eval mode."""
+    import random
+    torch.manual_seed(0)
+    random.seed(0)
+    rng = np.random.default_rng(0)
+    fs = 2
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2,
+                frame_stack=fs).to(DEV)
+    mae.initialize_training({"lr": 1e-3, "batch_size": 8})
+    buf = [{"image": rng.random((fs, 32, 32, 3), dtype=np.float32), "tactile": rng.random((fs, 6, 16, 16), dtype=np.float32) * 2 - 1}
+           for _ in range(16)]
+    before = {k: v.clone() for k, v in mae.state_dict().items()}
+    mae.train_iterations(3, buf[:4])                           # fewer samples than batch_size -> returns untouched
+    assert all(torch.equal(v, before[k]) for k, v in mae.state_dict().items())
+
+    from m3l_amd import vt_load
+    obs = {"image": np.stack([b["image"] for b in buf]).transpose(0, 2, 3, 1, 4).reshape(16, 32, 32, -1),
+           "tactile": np.stack([b["tactile"] for b in buf]).reshape(16, -1, 16, 16)}
+    xb = vt_load(obs, frame_stack=fs, device=DEV)
+    noises = [torch.rand(16, 16, device=DEV) for _ in range(3)]
+    with torch.no_grad():
+        l0 = float(mae(xb, mask_noise=noises))
+    mae.train_iterations(30, buf)
+    assert not mae.training
+    assert any(not torch.equal(v, before[k]) for k, v in mae.state_dict().items())
+    with torch.no_grad():
+        l1 = float(mae(xb, mask_noise=noises))
+    assert l1 < l0

@@ -105,6 +105,11 @@ def main():
     ap.add_argument("--roofline-kernel", default="gemm_nt_glds64", help="kernel class event-timed inside the timed region ('' = every tracked class, diagnostic)")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: time fwd+bwd without the Adam update")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the result: anything else a library prints there (RCCL's version banner goes to stdout)
+    # is sent to stderr by pointing fd 1 at fd 2 for the whole run and keeping the real stdout aside for the JSON line
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +118,13 @@ def main():
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_comm = os.environ.get("M3L_FORCE_COMM") == "1"       # rehearsal: RCCL calls at world size 1 (one-GPU box)
+    if world > 1 or force_comm or os.environ.get("M3L_FORCE_COMM") == "2":      # "2": process group only (diagnostic)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+        # RCCL kernels on a high-priority stream: a different hardware-queue pool from the compute stream, so collectives can
+        # never be serialised behind compute by HIP's stream -> queue multiplexing
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from m3l_amd import _lib
@@ -121,7 +132,7 @@ def main():
     _lib.lib()
     c = CFG2
     mae = build_model(c, args.dtype, dev)
-    sync = GradSync(mae)
+    sync = GradSync(mae, force_comm=force_comm)
     opt = FlatAdam(sync, lr=1e-4)                 # torch.optim.Adam semantics, one HIP launch over the flat buffers
     B = args.batch
     torch.manual_seed(1234 + rank)
@@ -139,7 +150,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -219,8 +230,8 @@ def main():
         out["model_tflops"] = round(total_flops / 1e12, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -39,7 +39,14 @@ int side_init() {
     int dev = 0;
     M3L_HIP(hipGetDevice(&dev));
     if (g_side.s && g_side.device == dev) return 0;
-    M3L_HIP(hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
+    // LOWEST stream priority, for two reasons.  (1) The work is off the critical path (weight gradients, next layers' weight
+    // casts).  (2) HIP multiplexes streams of one priority class onto a small pool of hardware queues; once a process holds
+    // many streams (torch's stream pool after torch.distributed initialises RCCL) a normal-priority side stream lands on the
+    // SAME hardware queue as the caller's stream and the two serialise (measured: -12 % step rate).  Each priority class has
+    // its own queue pool and nothing else in a torch process uses the lowest one.
+    int prio_least = 0, prio_greatest = 0;
+    M3L_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    M3L_HIP(hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_least));
     g_side.device = dev;
     g_side.ev.resize(64);
     for (auto& e : g_side.ev) M3L_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -180,7 +180,7 @@ class TransformerFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         sink = ctx.sink
         chunk = BWD_CHUNK_LAYERS
-        if chunk is None and sink is not None and sink[1] is not None and sink[0].world > 1:
+        if chunk is None and sink is not None and sink[1] is not None and sink[0]._comm:
             chunk = sink[0].layers_per_chunk
         if not chunk or chunk >= cfg.depth:
             L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,

@@ -11,6 +11,7 @@ torch.distributed (backend "nccl" == RCCL on ROCm) runs it on its own HIP stream
 stream — so the decoder's 7 MB travel while the encoder backward is still computing.  Parameters that never receive a
 gradient under sincos encodings (encoder.pos_embedding, decoder_pos_emb) are excluded (`grad is None`).
 """
+import os
 import re
 
 import torch
@@ -42,9 +43,11 @@ class GradSync:
 
     SKIP = ("encoder.pos_embedding", "decoder_pos_emb.weight")
 
-    def __init__(self, module: torch.nn.Module, process_group=None):
+    def __init__(self, module: torch.nn.Module, process_group=None, force_comm=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_comm: issue the collectives even at world size 1 (rehearses the RCCL stream / event path on a one-GPU box)
+        self._comm = self.world > 1 or (force_comm and dist.is_initialized())
         seen, named = set(), []
         for name, p in module.named_parameters():            # named_parameters() already de-duplicates shared tensors
             if id(p) in seen or not p.requires_grad or name in self.SKIP:
@@ -59,6 +62,8 @@ class GradSync:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)     # parameters re-homed into one buffer too
         self.layers_per_chunk = 4                              # transformer backward chunk size for comm / compute overlap
+        self.min_bucket_elems = int(os.environ.get("M3L_MIN_BUCKET_ELEMS", 1 << 20))   # 4 MB of fp32 gradients per collective
+        self._ready, self._sent_end = [], 0
         self._span = {}                                        # id(param) -> (start, end) in the flat buffer
         self.buckets = []                                      # (start, end, n_params)
         off, cur, start, count = 0, None, 0, 0
@@ -92,40 +97,59 @@ class GradSync:
     def zero_grad(self):
         self.flat.zero_()
         self._reduced = set()
+        self._ready, self._sent_end = [], 0
+
+    # The flat buffer is laid out in the order the backward finishes (heads -> decoder top-down -> glue -> encoder top-down ->
+    # embed), so finished spans grow a contiguous prefix.  A collective is issued for the finished-but-unsent prefix once it
+    # holds at least `min_bucket_elems` elements (few, large all-reduces: xGMI rings are latency-bound below a few MB), and
+    # finish() sends what is left.
+    def _span_ready(self, s, e, flush=False):
+        self._ready.append((s, e))
+        end, grew = self._sent_end, True
+        while grew:
+            grew = False
+            for a, b in self._ready:
+                if a <= end < b:
+                    end, grew = b, True
+        if end > self._sent_end and (flush or end - self._sent_end >= self.min_bucket_elems or end == self.flat.numel()):
+            self._works.append(dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._sent_end = end
 
     def bucket_done(self, bucket_id: int):
         """Called from the backward of the module that owns `bucket_id` once its gradients are in the flat buffer."""
         self._reduced.add(bucket_id)
-        if self.world <= 1 or bucket_id not in self._bucket_ids:
+        if not self._comm or bucket_id not in self._bucket_ids:
             return
         s, e, _ = self.buckets[self._bucket_ids.index(bucket_id)]
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._span_ready(s, e)
 
     def range_done(self, bucket_id: int, params, last: bool):
-        """Part of a bucket is final (a chunk of transformer layers): all-reduce just that contiguous slice."""
+        """Part of a bucket is final (a chunk of transformer layers): that contiguous slice may travel."""
         spans = [self._span[id(p)] for p in params if p is not None and id(p) in self._span]
         if last:
             self._reduced.add(bucket_id)
-        if self.world <= 1 or not spans:
+        if not self._comm or not spans:
             return
-        s, e = min(a for a, _ in spans), max(b for _, b in spans)
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._span_ready(min(a for a, _ in spans), max(b for _, b in spans))
 
     def finish(self):
-        """Reduce the buckets nobody reported (modules whose gradients come from several Functions), then make the compute
-        stream wait for every outstanding all-reduce (call before optimizer.step())."""
-        for b in self._bucket_ids:
-            if b not in self._reduced:
-                self.bucket_done(b)
+        """Send whatever has not travelled yet (buckets nobody reported: modules whose gradients come from several Functions),
+        then make the compute stream wait for every outstanding all-reduce (call before optimizer.step())."""
+        if self._comm:
+            for b in self._bucket_ids:
+                if b not in self._reduced:
+                    self.bucket_done(b)
+            if self._sent_end < self.flat.numel():
+                self._span_ready(self._sent_end, self.flat.numel(), flush=True)
         for w in self._works:
             w.wait()
-        if self._works:
+        if self._works and self.world > 1:
             self.flat.mul_(1.0 / self.world)       # SUM then scale: works on every backend (gloo has no AVG)
         self._works = []
 
     def reduce_now(self):
         """Non-overlapped variant (used by tests / when hooks are not wanted)."""
-        if self.world > 1:
+        if self._comm:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
 

@@ -491,3 +491,42 @@ def test_train_iterations_replay_buffer():
     with torch.no_grad():
         l1 = float(mae(xb, mask_noise=noises))
     assert l1 < l0
+
+
+def test_rccl_path_world1_matches_local():
+    """The multi-GPU step (GradSync buckets + chunked transformer backward + RCCL all-reduce on its own stream + FlatAdam)
+    rehearsed on ONE GPU: backend "nccl" (= RCCL) at world size 1 with force_comm, so every collective is really issued and
+    fenced; parameters after 3 steps must equal the no-communication run bit for bit (SUM over one rank, x 1/1)."""
+    import torch.distributed as dist
+    from m3l_amd.parallel import FlatAdam, GradSync
+
+    def run(force):
+        torch.manual_seed(0)
+        enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=6, heads=2, mlp_dim=128,
+                  num_tactiles=2)
+        mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=2, decoder_heads=2, num_tactiles=2,
+                    compute_dtype="bf16").to(DEV)
+        sync = GradSync(mae, force_comm=force)
+        assert sync._comm == force
+        opt = FlatAdam(sync, lr=1e-3)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x = {"image": torch.rand(8, 3, 32, 32, device=DEV, generator=g), "tactile1": torch.rand(8, 3, 16, 16, device=DEV, generator=g),
+             "tactile2": torch.rand(8, 3, 16, 16, device=DEV, generator=g)}
+        for _ in range(3):
+            noises = [torch.rand(8, 16, device=DEV, generator=g) for _ in range(3)]
+            sync.zero_grad()
+            mae(x, mask_noise=noises).backward()
+            sync.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        return sync.flat_params.clone(), sync.flat.clone()
+
+    p0, g0 = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        p1, g1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)

@@ -150,6 +150,10 @@ int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* imag
 /* ---- torch.optim.Adam semantics (models/ppo_mae.py:182-183) over one flat fp32 buffer of n elements; step counts from 1 */
 int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, void* stream);
+/* graph-capturable form: the step counter lives on the device (int, incremented by the call) together with the two bias
+ * corrections (float[2] scratch), so a captured launch stays correct on every replay (torch's Adam(capturable=True)) */
+int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int* step_dev, float* bias_corr_dev, void* stream);
 
 /* ---- in-library HIP-event timing of kernel classes (bench.py roofline).  filter: substring of "kind[AxBxC]" or NULL = all;
  * stride: bracket every stride-th matching launch (sampling keeps the perturbation of the timed region small). */

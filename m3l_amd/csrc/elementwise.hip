@@ -372,9 +372,14 @@ __global__ __launch_bounds__(256) void tokens_assemble_bwd_kernel(const float* _
 // Adam over ONE flat parameter / gradient / moment buffer (reference optimizer: torch.optim.Adam(mae.parameters(), lr=1e-4),
 // models/ppo_mae.py:182-183): same update rule and operation order as torch's, one launch for all 7.3 M parameters.
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                 long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                 long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                 const float* __restrict__ bc_dev) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
+    if (bc_dev) {            // graph-capturable form: bias corrections of the device-side step counter
+        bc1 = bc_dev[0];
+        bc2_sqrt = bc_dev[1];
+    }
     if (i + 4 <= n) {
         f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
         f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
@@ -397,6 +402,14 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
             p[k] = p[k] - (lr / bc1) * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
         }
     }
+}
+
+// step += 1; bias corrections 1 - beta^step in double (as torch's Python-float arithmetic), for the capturable Adam
+__global__ void adam_bias_kernel(int* __restrict__ step, float b1, float b2, float* __restrict__ bc) {
+    const int t = *step + 1;
+    *step = t;
+    bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
 }
 
 // vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW (normalisation [0,1] is the identity);
@@ -930,7 +943,17 @@ int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr
     M3L_CHECK(n > 0 && step >= 1, "adam: n=%ld step=%d", n, step);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
-    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, nullptr);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                      int* step_dev, float* bc_dev, hipStream_t st) {
+    M3L_CHECK(n > 0 && step_dev && bc_dev, "adam (device step): n=%ld", n);
+    adam_bias_kernel<<<1, 1, 0, st>>>(step_dev, b1, b2, bc_dev);
+    M3L_LAUNCH_CHECK();
+    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, 1.0f, 1.0f, bc_dev);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -1023,6 +1023,12 @@ int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
+int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int* step_dev, float* bias_corr_dev, void* stream) {
+    return m3l_adam_flat_dev(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, bias_corr_dev,
+                             (hipStream_t)stream);
+}
+
 int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                    const float* res, float* out_f32, void* out_t, void* out_pre, const void* gelu_u, int act, int ldc, void* stream) {
     GemmEpi e = epi0(ldc);

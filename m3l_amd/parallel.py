@@ -158,11 +158,16 @@ class FlatAdam:
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) semantics (the reference's MAE optimizer, ppo_mae.py:182-183)
     as ONE HIP launch over the GradSync's flat parameter / gradient buffers (m3l_adam_step)."""
 
-    def __init__(self, sync: GradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, sync: GradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         self.sync, self.lr, self.betas, self.eps, self.weight_decay = sync, lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(sync.flat)
         self.exp_avg_sq = torch.zeros_like(sync.flat)
         self.step_count = 0
+        # capturable (as torch.optim.Adam(capturable=True)): the step counter lives on the device, so step() can be recorded
+        # into a HIP graph and replayed
+        self.capturable = capturable
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=sync.flat.device) if capturable else None
+        self._bc_dev = torch.zeros(2, dtype=torch.float32, device=sync.flat.device) if capturable else None
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay, "params": sync.params}]
 
     def zero_grad(self, set_to_none: bool = False):
@@ -170,17 +175,25 @@ class FlatAdam:
 
     def step(self):
         from . import _lib as L
-        self.step_count += 1
         g = self.param_groups[0]
+        if self.capturable:
+            L.check(L.lib().m3l_adam_step_dev(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                              g["eps"], g["weight_decay"], self._step_dev.data_ptr(), self._bc_dev.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "m3l_adam_step_dev")
+            return
+        self.step_count += 1
         L.check(L.lib().m3l_adam_step(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
                                       g["eps"], g["weight_decay"], self.step_count, torch.cuda.current_stream().cuda_stream),
                 "m3l_adam_step")
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
+        return {"step": int(self._step_dev.item()) if self.capturable else self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        if self.capturable:
+            self._step_dev.fill_(self.step_count)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

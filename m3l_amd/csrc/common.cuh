@@ -124,24 +124,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. below fp32 GELU round-off for the parity tolerance): one
-// v_exp, one v_rcp and five FMAs instead of the ~40-instruction branchy libm erff — the GEMM epilogues evaluate it
-// 10^8 times per step.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+// GELU (erf form, as torch.nn.GELU()) and its derivative from ONE shared evaluation.  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, below fp32 GELU round-off for the parity tolerance): with a = |x|/sqrt(2), t = 1/(1 + p a),
+//   erf(a) = 1 - (a1 t + ... + a5 t^5) exp(-a^2),   and exp(-a^2) = exp(-x^2/2) is also the Gaussian pdf of the derivative.
+// Cost per element: one v_exp_f32 and one v_rcp_f32 (quarter-rate) + ~10 full-rate ops — the GEMM epilogues evaluate this
+// 10^8 times per step and are VALU-bound on it, so no IEEE division (v_div_scale/fmas/fixup = 10 more ops) and no second exp.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(y, x);
+    e = __expf(-ax * ax);
+    const float y = 1.0f - p * t * e;                      // erf(|x| / sqrt 2)
+    cdf = fmaf(0.5f, copysignf(y, x), 0.5f);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float erf_fast(float x) {
+    float cdf, e;
+    gelu_parts(x * 1.41421356237309504880f, cdf, e);
+    return 2.0f * cdf - 1.0f;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 // ---- host side -------------------------------------------------------------------------------------

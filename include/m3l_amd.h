@@ -88,6 +88,16 @@ int m3l_transformer_bwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
 int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_in, const void* const* tensors, void* ws,
                               const void* dy, int dy_dtype, float* dx_in, float* const* grads, int layer_hi, int layer_lo, void* stream);
 
+/* ---- frozen ViT forward (inference only): the DINOv2-S/14-reg image feature of the cfg-5 fusion head
+ * (models/pretrain_models_dino_cat_mae.py:886 `self.dino_model(obs_viso)`; train_dino_cat_mae.py:29).  x: tokens (B, n, dim) f32
+ * (cls + registers + patches, positions already added); y32: final-norm output (B, n, dim) f32.
+ * tensors: per layer 12 pointers {norm1.w, norm1.b, qkv.W[3*heads*64, dim], qkv.b, proj.W[dim, heads*64], proj.b, norm2.w, norm2.b,
+ * fc1.W[mlp, dim], fc1.b, fc2.W[dim, mlp], fc2.b}, then {norm.w, norm.b}.  The four W are in the COMPUTE type (c->dtype; they
+ * never change, so the caller casts once), everything else f32; LayerScale is folded into proj / fc2 by the caller. */
+size_t m3l_frozen_vit_ws_bytes(const m3l_tf_cfg* c, int B, int n);
+int m3l_frozen_vit_fwd(const m3l_tf_cfg* c, float ln_eps, int B, int n, const float* x, const void* const* tensors, void* ws,
+                       float* y32, void* stream);
+
 /* ---- encoder -> decoder glue.  enc32 / enc_t: final-norm output of the encoder (B, nvis, D) in f32 / compute type.
  * tensors: {e2d_w[dd,D] or NULL, e2d_b or NULL, mask_token[dd], dec_mod[(1+k),dd], pos_img_dec[n_img,dd], pos_tac_dec[k*n_tac,dd]} */
 size_t m3l_unshuffle_ws_bytes(const m3l_geom* g, int D, int dd, int dtype, int B, int nvis, int nmask);

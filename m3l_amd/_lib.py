@@ -41,6 +41,8 @@ _SIGS = {
     "m3l_transformer_fwd": (c_i, [C.POINTER(TfCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_transformer_bwd": (c_i, [C.POINTER(TfCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "m3l_transformer_bwd_range": (c_i, [C.POINTER(TfCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "m3l_frozen_vit_ws_bytes": (c_sz, [C.POINTER(TfCfg), c_i, c_i]),
+    "m3l_frozen_vit_fwd": (c_i, [C.POINTER(TfCfg), C.c_float, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "m3l_unshuffle_ws_bytes": (c_sz, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i]),
     "m3l_unshuffle_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_unshuffle_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

@@ -476,7 +476,8 @@ __device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, 
 }
 
 // gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
-template <typename T>
+// NV = elements per lane: 16 for patch dims <= 1024, 40 for <= 2560 (cfg 5: 14x14 patches of 4 stacked RGB frames = 2352)
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
                                                          int rows, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, T* __restrict__ xn, int pdpad) {
@@ -485,10 +486,10 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     const int pd = pg.C * pg.P * pg.P;
     int b, s, ph, pw, local;
     patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-    float v[MAXV];
+    float v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
         sum += v[i];
@@ -496,14 +497,14 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     const float mean = wave_sum(sum) / pd;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         const float d = (e < pd) ? v[i] - mean : 0.f;
         q += d * d;
     }
     const float rstd = rsqrtf(wave_sum(q) / pd + eps);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         if (e < pd)
             xn[(long)row * pdpad + e] = from_f32<T>((v[i] - mean) * rstd * gamma[e] + beta[e]);
@@ -513,23 +514,23 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
 }
 
 // backward of the first patch LayerNorm w.r.t. its affine parameters (the input is data): part[G][2*pd]
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
                                                              int rows, float eps, const T* __restrict__ dxn, int pdpad,
                                                              float* __restrict__ part) {
     __shared__ float red[WPB][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
-    float dg[MAXV], db[MAXV];
+    float dg[NV], db[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) dg[i] = db[i] = 0.f;
+    for (int i = 0; i < NV; ++i) dg[i] = db[i] = 0.f;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         int b, s, ph, pw, local;
         patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-        float v[MAXV];
+        float v[NV];
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = lane + 64 * i;
             v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
             sum += v[i];
@@ -537,14 +538,14 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         const float mean = wave_sum(sum) / pd;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = lane + 64 * i;
             const float d = (e < pd) ? v[i] - mean : 0.f;
             q += d * d;
         }
         const float rstd = rsqrtf(wave_sum(q) / pd + eps);
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = lane + 64 * i;
             if (e < pd) {
                 const float d = to_f32(dxn[(long)row * pdpad + e]);
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
     }
     float* out = part + (long)blockIdx.x * 2 * pd;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (64 * i >= pd) break;
         red[wave][lane] = dg[i];
         red[wave][64 + lane] = db[i];
@@ -996,10 +997,11 @@ int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, in
     return 0;
 }
 
+constexpr int PATCH_NV_MAX = 40;
 static int check_pg(const PatchGroup& pg) {
     const int pd = pg.C * pg.P * pg.P;
     M3L_CHECK(pg.nsrc >= 1 && pg.nsrc <= M3L_MAX_SENSORS, "patch group: nsrc=%d", pg.nsrc);
-    M3L_CHECK(pd <= 64 * MAXV, "patch dim %d > %d unsupported", pd, 64 * MAXV);
+    M3L_CHECK(pd <= 64 * PATCH_NV_MAX, "patch dim %d > %d unsupported", pd, 64 * PATCH_NV_MAX);
     M3L_CHECK(pg.H % pg.P == 0 && pg.W % pg.P == 0, "image dims must be divisible by the patch size");
     return 0;
 }
@@ -1009,10 +1011,14 @@ int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld
     if (check_pg(*pg)) return 1;
     const int rows = B * cnt;
     if (rows == 0) return 0;
-    if (dtype == 1)
-        patch_ln_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (bf16*)xn, pdpad);
-    else
-        patch_ln_kernel<float><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (float*)xn, pdpad);
+    const bool wide = pg->C * pg->P * pg->P > 64 * MAXV;
+#define PATCH_LN(T, NV) patch_ln_kernel<T, NV><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (T*)xn, pdpad)
+    if (dtype == 1) {
+        if (wide) PATCH_LN(bf16, PATCH_NV_MAX); else PATCH_LN(bf16, MAXV);
+    } else {
+        if (wide) PATCH_LN(float, PATCH_NV_MAX); else PATCH_LN(float, MAXV);
+    }
+#undef PATCH_LN
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1024,10 +1030,14 @@ int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int id
     if (rows == 0) return 0;
     const int pd = pg->C * pg->P * pg->P;
     const int G = part_grid(rows);
-    if (dtype == 1)
-        patch_ln_bwd_kernel<bf16><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const bf16*)dxn, pdpad, part_ws);
-    else
-        patch_ln_bwd_kernel<float><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const float*)dxn, pdpad, part_ws);
+    const bool wide = pd > 64 * MAXV;
+#define PATCH_LN_BWD(T, NV) patch_ln_bwd_kernel<T, NV><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const T*)dxn, pdpad, part_ws)
+    if (dtype == 1) {
+        if (wide) PATCH_LN_BWD(bf16, PATCH_NV_MAX); else PATCH_LN_BWD(bf16, MAXV);
+    } else {
+        if (wide) PATCH_LN_BWD(float, PATCH_NV_MAX); else PATCH_LN_BWD(float, MAXV);
+    }
+#undef PATCH_LN_BWD
     M3L_LAUNCH_CHECK();
     reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws, G, 2 * pd, pd, dgamma, accumulate);
     reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws + pd, G, 2 * pd, pd, dbeta, accumulate);

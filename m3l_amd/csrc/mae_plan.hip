@@ -618,6 +618,72 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// frozen ViT (inference only): the DINOv2-S/14-reg feature extractor of the cfg-5 fusion head
+// (models/pretrain_models_dino_cat_mae.py:886 `self.dino_model(obs_viso)`; train_dino_cat_mae.py:29 torch.hub dinov2_vits14_reg).
+// Same kernels as the trainable transformer, no saved activations, weights handed over already in the compute type (they never
+// change), qkv WITH bias, caller-chosen LayerNorm eps (1e-6), LayerScale folded into the out-proj / fc2 weights by the caller.
+namespace {
+struct FvWs {
+    void *xn, *qkv, *o, *h;
+    float *xa, *xb, *lse;
+    size_t total;
+};
+FvWs fv_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
+    Arena a(ws);
+    FvWs w;
+    const size_t M = (size_t)B * n, e = esz(c->dtype), HD = (size_t)c->heads * 64;
+    w.xn = a.take(M * c->dim * e);
+    w.qkv = a.take(M * 3 * HD * e);
+    w.o = a.take(M * HD * e);
+    w.h = a.take(M * c->mlp_dim * e);
+    w.xa = a.take_n<float>(M * c->dim);
+    w.xb = a.take_n<float>(M * c->dim);
+    w.lse = a.take_n<float>((size_t)B * c->heads * n);
+    w.total = a.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t m3l_frozen_vit_ws_bytes(const m3l_tf_cfg* c, int B, int n) {
+    if (check_tf(c, B, n)) return 0;
+    return fv_layout(c, B, n, nullptr).total;
+}
+
+int m3l_frozen_vit_fwd(const m3l_tf_cfg* c, float ln_eps, int B, int n, const float* x_in, const void* const* tensors, void* ws,
+                       float* y32, void* stream) {
+    if (check_tf(c, B, n)) return 1;
+    M3L_CHECK(c->project_out, "frozen_vit: the block always has an output projection");
+    M3L_CHECK(ln_eps > 0.f && x_in && tensors && ws && y32, "frozen_vit: null argument / eps");
+    hipStream_t st = (hipStream_t)stream;
+    FvWs w = fv_layout(c, B, n, ws);
+    const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
+    const float* x = x_in;
+    for (int l = 0; l < c->depth; ++l) {
+        const void* const* t = tensors + 12 * l;
+        float* x1 = w.xa;                          // x -> x1 (attention branch) -> x2 (MLP branch); x is x_in or xb
+        float* x2 = w.xb;
+        if (m3l_ln_fwd(dt, x, M, D, (const float*)t[0], (const float*)t[1], ln_eps, w.xn, nullptr, st)) return 1;
+        GemmEpi e = epi0(3 * HD);
+        e.bias = (const float*)t[3]; e.out_t = w.qkv;
+        if (m3l_gemm_nt(dt, w.xn, D, t[2], D, M, 3 * HD, D, &e, st)) return 1;
+        if (m3l_attn_fwd(dt, w.qkv, w.o, w.lse, B, n, c->heads, st)) return 1;
+        e = epi0(D);
+        e.bias = (const float*)t[5]; e.res = x; e.out_f32 = x1;
+        if (m3l_gemm_nt(dt, w.o, HD, t[4], HD, M, D, HD, &e, st)) return 1;
+        if (m3l_ln_fwd(dt, x1, M, D, (const float*)t[6], (const float*)t[7], ln_eps, w.xn, nullptr, st)) return 1;
+        e = epi0(mlp);
+        e.bias = (const float*)t[9]; e.act = 1; e.out_t = w.h;
+        if (m3l_gemm_nt(dt, w.xn, D, t[8], D, M, mlp, D, &e, st)) return 1;
+        e = epi0(D);
+        e.bias = (const float*)t[11]; e.res = x1; e.out_f32 = x2;
+        if (m3l_gemm_nt(dt, w.h, mlp, t[10], mlp, M, D, mlp, &e, st)) return 1;
+        x = x2;
+    }
+    const void* const* tf = tensors + 12 * c->depth;
+    return m3l_ln_fwd(0, x, M, D, (const float*)tf[0], (const float*)tf[1], ln_eps, nullptr, y32, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // encoder -> decoder glue
 namespace {
 struct UnWs {

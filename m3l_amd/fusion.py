@@ -1,0 +1,64 @@
+"""cfg-5 fusion head: MAE token embeddings + a frozen DINOv2 image feature -> policy features
+(reference: `MAEExtractor` in models/pretrain_models_dino_cat_mae.py:793-904, built by train_dino_cat_mae.py:140-197).
+
+    obs --vt_load--> x --mae.get_embeddings--> (B, N, D) --1-layer Transformer--> mean over tokens --+
+    x['image'][:, middle RGB frame] --frozen DINOv2-S/14-reg--> (B, D) ------------------------------cat--> MLP (2D -> 2D -> 2D -> D)
+
+Everything up to the concat runs on this package's HIP kernels (VTMAE.get_embeddings, Transformer, DinoV2Frozen); the three-Linear
+fusion MLP on a (B, 2D) matrix is a plain library GEMM (torch.nn.Linear -> hipBLASLt) with Dropout(0.1) exactly as the reference builds it.
+
+The reference class derives from stable-baselines3's `BaseFeaturesExtractor`; SB3 is not part of this package, so this is a plain
+`nn.Module` with the same constructor arguments after `observation_space`, the same sub-module / parameter names (`vit_layer`,
+`mlp`, `query`, `query_projection`, `key_projection` — the last three are created but unused by the reference's forward too) and
+`features_dim`.  INTEGRATION.md shows the two-line SB3 wrapper.
+
+Reference defect NOT reproduced: the middle-frame slice `image[:, 3*mid-3 : 3*mid]` with `mid = frame_stack // 2`
+(:883-885) is EMPTY for frame_stack == 1; here frame_stack == 1 uses the only frame (channels 0..2).
+"""
+import torch
+import torch.nn as nn
+
+from .pretrain_models import VTT
+from .pretrain_utils import vt_load
+
+
+class DinoCatMAEExtractor(nn.Module):
+    def __init__(self, dino_model, mae_model, dim_embeddings, vision_only_control, frame_stack, observation_space=None):
+        super().__init__()
+        self.features_dim = dim_embeddings
+        self.dim_embeddings = dim_embeddings
+        self.flatten = nn.Flatten()
+        self.mae_model = mae_model
+        self.dino_model = dino_model
+        self.running_buffer = {}
+        self.vision_only_control = vision_only_control
+        self.frame_stack = frame_stack
+        self.vit_layer = VTT(image_size=(70, 70), tactile_size=(70, 70), image_patch_size=14, tactile_patch_size=14,   # sizes unused:
+                             dim=dim_embeddings, depth=1, heads=4, mlp_dim=dim_embeddings * 2, num_tactiles=2)        # only .transformer runs
+        self.mlp = nn.Sequential(nn.Linear(dim_embeddings * 2, dim_embeddings * 2), nn.ReLU(), nn.Dropout(0.1),
+                                 nn.Linear(dim_embeddings * 2, dim_embeddings * 2), nn.ReLU(), nn.Dropout(0.1),
+                                 nn.Linear(dim_embeddings * 2, dim_embeddings))
+        self.query = nn.Parameter(torch.randn(1, 1, dim_embeddings))
+        self.query_projection = nn.Linear(dim_embeddings, dim_embeddings)
+        self.key_projection = nn.Linear(dim_embeddings, dim_embeddings)
+
+    def middle_frame(self, image):
+        """(B, 3*fs, H, W) -> (B, 3, H, W): frame fs // 2 - 1 as the reference slices it (:883-885); the only frame when fs == 1."""
+        mid = self.frame_stack // 2
+        lo = 3 * mid - 3 if mid >= 1 else 0
+        return image[:, lo:lo + 3]
+
+    def forward(self, observations):
+        obs = dict(observations)
+        if "image" in obs and len(obs["image"].shape) == 5:          # (B, fs, H, W, 3) -> (B, H, W, 3*fs)
+            im = obs["image"].permute(0, 2, 3, 1, 4)
+            obs["image"] = im.reshape(im.shape[0], im.shape[1], im.shape[2], -1)
+        if "tactile" in obs and len(obs["tactile"].shape) == 5:      # (B, fs, 6, h, w) -> (B, 6*fs, h, w)
+            t = obs["tactile"]
+            obs["tactile"] = t.reshape(t.shape[0], -1, t.shape[3], t.shape[4])
+        dev = self.query.device
+        vt = vt_load(obs, frame_stack=self.frame_stack, device=dev)
+        tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
+        dino = self.dino_model(self.middle_frame(vt["image"]))
+        pooled = torch.mean(self.vit_layer.transformer(tokens), dim=1)
+        return self.mlp(torch.cat((self.flatten(pooled), dino.to(pooled.dtype)), dim=-1))

@@ -122,3 +122,24 @@ def test_dino_vtt_state_dict_and_pos_table(golden_dir):
     assert float(enc.norm.weight.min()) == 1.0 and float(enc.transformer.layers[0][1].net[1].bias.abs().max()) == 0.0
     assert abs(float(enc.image_to_patch_embedding[2].weight.std()) - 0.02) < 0.002
     enc.load_state_dict({k: torch.tensor(z["param/" + k]) for k in ref_keys}, strict=True)
+
+
+def test_dinov2_frozen_surface(golden_dir):
+    """DinoV2Frozen: hub-checkpoint state-dict names / shapes (the fixture stores them under those names), everything frozen,
+    no CPU execution path."""
+    import os
+    import numpy as np
+    import pytest
+    import torch
+    from m3l_amd import DinoV2Frozen, M3LError
+    z = np.load(os.path.join(golden_dir, "dinov2_small.npz"))
+    dim, depth, heads, patch, img, reg = [int(v) for v in z["meta"]]
+    m = DinoV2Frozen(embed_dim=dim, depth=depth, num_heads=heads, patch_size=patch, img_size=img, num_register_tokens=reg)
+    want = {k[len("param/"):]: tuple(z[k].shape) for k in z.files if k.startswith("param/")}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    m.load_state_dict({k: torch.tensor(z["param/" + k]) for k in want}, strict=True)
+    assert not any(p.requires_grad for p in m.parameters()) and not m.training
+    with pytest.raises(M3LError):
+        m(torch.zeros(1, 3, 70, 70))
+    full = DinoV2Frozen()                                   # dinov2_vits14_reg sizes
+    assert sum(p.numel() for p in full.parameters()) == 22_058_112   # == transformers' Dinov2WithRegistersModel at ViT-S/14, 4 registers

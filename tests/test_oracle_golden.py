@@ -180,3 +180,17 @@ def test_reconstruct(golden_dir, name):
             np.testing.assert_array_equal(a, b)               # raw pixels + fill values: exact
         else:
             np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_dinov2_oracle_vs_independent_implementation(golden_dir):
+    """oracle/dinov2_oracle.py (restated facebookresearch/dinov2 ViT with registers) against transformers' implementation of the
+    same architecture (tests/golden/make_golden_dinov2.py): tokens incl. interpolated positions, all normed tokens, CLS feature."""
+    from oracle import dinov2_oracle as D
+    z = _load(golden_dir, "dinov2_small")
+    dim, depth, heads, patch, _, _ = [int(v) for v in z["meta"]]
+    P = {k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    with torch.no_grad():
+        r = D.dinov2_forward(P, torch.tensor(z["input/x"]), patch=patch, depth=depth, heads=heads)
+    np.testing.assert_allclose(r["tokens_in"].numpy(), z["out/tokens_in"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["x_norm"].numpy(), z["out/x_norm"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["cls"].numpy(), z["out/cls"], rtol=1e-4, atol=1e-5)

@@ -351,6 +351,16 @@ def test_cfg5_shapes_patch14():
     assert mae.last_mask[1].shape == (3, 15)
 
 
+def test_cfg5_frame_stack4_patch_dim_2352():
+    """cfg 5 at the reference's default --frame_stack 4 (train_dino_cat_mae.py:69,149-151): 12-channel 14x14 patches, patch dim 2352
+    (> 1024: the wide patch-LayerNorm kernels), loss and every gradient against the oracle."""
+    cfg = O.OracleCfg(70, 70, 14, 14, 128, 1, 2, 256, 12, 2, 128, 1, 2, 0.8)
+    _parity_vs_oracle(dict(image_size=70, tactile_size=70, image_patch_size=14, tactile_patch_size=14, dim=128, depth=1, heads=2,
+                           mlp_dim=256, image_channels=12, tactile_channels=12, num_tactiles=2, frame_stack=4),
+                      dict(decoder_dim=128, masking_ratio=0.8, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=4),
+                      B=2, C=12, hw_img=70, hw_tac=70, k=2, cfg=cfg)
+
+
 def test_flat_adam_matches_torch_adam():
     """FlatAdam (one HIP launch over the flat parameter buffer) == torch.optim.Adam step for step (reference optimizer,
     ppo_mae.py:182-183), including weight decay."""
@@ -530,3 +540,110 @@ def test_rccl_path_world1_matches_local():
     finally:
         dist.destroy_process_group()
     assert torch.equal(g0, g1) and torch.equal(p0, p1)
+
+
+# ---- cfg-5 fusion head: frozen DINOv2 encoder + concat extractor -------------------------------------------------
+def _dino_from_fixture(z, compute_dtype):
+    from m3l_amd import DinoV2Frozen
+    dim, depth, heads, patch, img, reg = [int(v) for v in z["meta"]]
+    m = DinoV2Frozen(embed_dim=dim, depth=depth, num_heads=heads, patch_size=patch, img_size=img, num_register_tokens=reg,
+                     compute_dtype=compute_dtype)
+    m.load_state_dict({k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("compute_dtype,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
+def test_dinov2_frozen_golden(golden_dir, compute_dtype, tol):
+    """m3l_frozen_vit_fwd against the independent implementation's outputs (tests/golden/dinov2_small.npz): interpolated
+    positions + registers (exact data movement in fp32), every normed token, the CLS feature."""
+    z = np.load(os.path.join(golden_dir, "dinov2_small.npz"))
+    m = _dino_from_fixture(z, compute_dtype)
+    x = torch.tensor(z["input/x"]).to(DEV)
+    f = m.forward_features(x)
+    cls = m(x)
+    assert torch.equal(cls, f["x_norm_clstoken"]) and cls.shape == (2, 64) and not cls.requires_grad
+    scale = float(np.abs(z["out/x_norm"]).max())
+    np.testing.assert_allclose(f["tokens_in"].cpu().numpy(), z["out/tokens_in"], rtol=0, atol=(2e-2 if compute_dtype == "bf16" else 2e-5))
+    y = torch.cat((f["x_norm_clstoken"][:, None], f["x_norm_regtokens"], f["x_norm_patchtokens"]), 1).cpu().numpy()
+    assert np.abs(y - z["out/x_norm"]).max() <= tol * scale
+    assert np.abs(cls.cpu().numpy() - z["out/cls"]).max() <= tol * scale
+
+
+def test_dinov2_frozen_vits14_reg_vs_transformers_live():
+    """Full dinov2_vits14_reg architecture (384 / 12 layers / 6 heads / 4 registers, position table for 518x518 interpolated to the
+    5x5 grid of a 70x70 frame), random frozen weights: our HIP forward against transformers' CPU forward of the same weights."""
+    transformers = pytest.importorskip("transformers")
+    from m3l_amd import DinoV2Frozen
+    from oracle.dinov2_oracle import hf_to_hub_state_dict
+    torch.manual_seed(7)
+    hf = transformers.Dinov2WithRegistersModel(transformers.Dinov2WithRegistersConfig(
+        hidden_size=384, num_hidden_layers=12, num_attention_heads=6, patch_size=14, image_size=518, num_register_tokens=4)).eval()
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if "lambda" in n:
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))           # non-trivial LayerScale
+            elif p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.rand(4, 3, 70, 70, generator=g)
+    with torch.no_grad():
+        ref = hf(x).pooler_output
+    m = DinoV2Frozen()
+    m.load_state_dict(hf_to_hub_state_dict(hf.state_dict()), strict=True)
+    m = m.to(DEV)
+    scale = ref.abs().max().item()
+    for cd, tol in (("fp32", 5e-4), ("bf16", 5e-2)):
+        m.set_compute_dtype(cd)
+        out = m(x.to(DEV)).cpu()
+        assert out.shape == (4, 384)
+        assert (out - ref).abs().max().item() <= tol * scale, (cd, (out - ref).abs().max().item(), scale)
+    # frozen-weight cache follows the parameters: an in-place change must be picked up
+    with torch.no_grad():
+        m.norm.bias.add_(1.0)
+    assert (m(x.to(DEV)).cpu() - (ref + 0)).abs().max().item() > 0.5 * 1.0 - 5e-2 * scale
+
+
+def test_dino_cat_extractor_cfg5():
+    """cfg-5 geometry (70x70, P = 14, 2 tactile 70x70, frame_stack 4 = the reference default, dim 384 reduced to 128 for speed): DinoCatMAEExtractor against
+    the same pipeline composed from the CPU oracles (get_embeddings -> 1-layer Transformer -> mean | DINOv2 CLS -> cat -> MLP), and
+    gradients reach the MAE encoder, the extra transformer layer and the MLP but not the frozen DINOv2."""
+    from m3l_amd import DinoCatMAEExtractor, DinoV2Frozen
+    from oracle import dinov2_oracle as DO
+    torch.manual_seed(3)
+    fs, D = 4, 128
+    enc = VTT(image_size=70, tactile_size=70, image_patch_size=14, tactile_patch_size=14, dim=D, depth=2, heads=4, mlp_dim=2 * D,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=D, masking_ratio=0.8, decoder_depth=1, decoder_heads=4, num_tactiles=2, frame_stack=fs).to(DEV)
+    dino = DinoV2Frozen(embed_dim=D, depth=2, num_heads=2, img_size=98, compute_dtype="fp32")
+    with torch.no_grad():
+        for p in dino.parameters():
+            p.copy_(0.2 * torch.randn(p.shape))
+        dino.norm.weight.fill_(1.0)
+    dino = dino.to(DEV)
+    ext = DinoCatMAEExtractor(dino, mae, D, vision_only_control=False, frame_stack=fs).to(DEV).eval()      # eval: Dropout off
+    assert ext.features_dim == D
+    rng = np.random.default_rng(0)
+    B = 3
+    obs = {"image": torch.tensor(rng.random((B, fs, 70, 70, 3), dtype=np.float32)).to(DEV),
+           "tactile": torch.tensor(rng.random((B, fs, 6, 70, 70), dtype=np.float32) * 2 - 1).to(DEV)}
+    out = ext(obs)
+    assert out.shape == (B, D)
+    out.square().mean().backward()
+    assert mae.encoder.transformer.layers[0][0].to_qkv.weight.grad is not None
+    assert ext.vit_layer.transformer.layers[0][1].net[1].weight.grad is not None and ext.mlp[0].weight.grad is not None
+    assert all(p.grad is None for p in dino.parameters())
+
+    # the same numbers from the CPU oracles
+    x = O.vt_load({"image": obs["image"].cpu().permute(0, 2, 3, 1, 4).reshape(B, 70, 70, -1).numpy(),
+                   "tactile": obs["tactile"].cpu().reshape(B, -1, 70, 70).numpy()}, frame_stack=fs)
+    P = {k: v.detach().cpu() for k, v in mae.state_dict().items()}
+    cfg = O.OracleCfg(70, 70, 14, 14, D, 2, 4, 2 * D, 3 * fs, 2, D, 1, 4, 0.8)
+    with torch.no_grad():
+        tok = O.get_embeddings(P, cfg, x)
+        PL = {k: v.detach().cpu() for k, v in ext.vit_layer.state_dict().items()}
+        pooled = O.transformer(tok, PL, "transformer.", 1, 4, 64).mean(1)
+        PD = {k: v.detach().cpu() for k, v in dino.state_dict().items()}
+        cls = DO.dinov2_forward(PD, x["image"][:, 3:6], patch=14, depth=2, heads=2)["cls"]   # fs = 4: mid = 2 -> channels 3..5
+        ref = ext.mlp.cpu()(torch.cat((pooled, cls), -1))
+    ext.mlp.to(DEV)
+    assert (out.detach().cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-5

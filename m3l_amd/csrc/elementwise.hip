@@ -209,6 +209,40 @@ __global__ __launch_bounds__(1024) void reduce_rows_seg_kernel(const float* __re
     }
 }
 
+// the same reduction for MANY partial slabs in one launch (blockIdx.z = slab): the dgamma / dbeta / bias-gradient partials of every
+// LayerNorm backward of a transformer stack are reduced once, off the critical path, instead of by one small launch per LayerNorm
+__global__ __launch_bounds__(1024) void reduce_rows_batch_kernel(ReduceBatch b, int accumulate) {
+    __shared__ float red[32][33];
+    const ReduceBatchItem it = b.it[blockIdx.z];
+    float* out = it.out[blockIdx.y];
+    if (!out) return;                            // uniform per block
+    const int width = b.D, stride = 3 * b.D, G = it.G;
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cl;
+    const float* p = it.part + (long)blockIdx.y * width;
+    float s = 0.f;
+    if (j < width) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = sl;
+        for (; g + 96 < G; g += 128) {
+            s0 += p[(long)g * stride + j];
+            s1 += p[(long)(g + 32) * stride + j];
+            s2 += p[(long)(g + 64) * stride + j];
+            s3 += p[(long)(g + 96) * stride + j];
+        }
+        for (; g < G; g += 32) s0 += p[(long)g * stride + j];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && j < width) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) t += red[i][cl];
+        out[j] = accumulate ? out[j] + t : t;
+    }
+}
+
 // column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, rows strided by grid
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int M, int N, int ld, int rows_per_block,
@@ -818,13 +852,19 @@ int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out,
     return 0;
 }
 
+// number of partial rows [G][3 D] one ln_bwd launch writes
+int m3l_ln_bwd_blocks(int M) {
+    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 8 workgroups per CU
+    if (G > 2048) G = 2048;
+    return G < 1 ? 1 : G;
+}
+
+// dgamma == dbeta == dbias == nullptr: leave the partials in part_ws for a later m3l_reduce_rows_batch
 int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const float* gamma, float eps, const float* dres,
                float* dx_out, void* dx_t_out, int ct_dtype, float* part_ws, float* dgamma, float* dbeta, float* dbias,
                int accumulate, hipStream_t st) {
     M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "ln_bwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
-    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 8 workgroups per CU
-    if (G > 2048) G = 2048;
-    if (G < 1) G = 1;
+    const int G = m3l_ln_bwd_blocks(M);
     {
         ProfScope prof("ln_bwd", M, D, dy_dtype,
                        (double)M * D * (4.0 + (dy_dtype ? 2 : 4) + (dres ? 4 : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
@@ -837,8 +877,18 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
 #undef LN_BWD
     }
     M3L_LAUNCH_CHECK();
+    if (!dgamma && !dbeta && !dbias) return 0;
     ReduceSegs segs = {{dgamma, dbeta, dbias, nullptr}};
     reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 3), 1024, 0, st>>>(part_ws, G, 3 * D, D, segs, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_reduce_rows_batch(const ReduceBatch* b, int accumulate, hipStream_t st) {
+    if (b->count <= 0) return 0;
+    M3L_CHECK(b->count <= M3L_REDUCE_BATCH_MAX && b->D > 0, "reduce_rows_batch: count=%d D=%d", b->count, b->D);
+    ProfScope prof("reduce_batch", b->count, b->D, 0, 0.0, st);
+    reduce_rows_batch_kernel<<<dim3(cdiv(b->D, 32), 3, b->count), 1024, 0, st>>>(*b, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }

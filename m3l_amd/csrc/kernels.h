@@ -76,6 +76,19 @@ bool m3l_gemm_nt_rowln_supported(int dtype, int N, int K);
 int m3l_gemm_nt_rowln(int dtype, int mode, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const RowLnEpi* ep,
                       hipStream_t st);
 // out_i[j] = sum_g part[g*3*D + i*D + j], i = 0..2 (null outputs skipped): reduction of the LayerNorm-backward partial slabs
+// many [G][3 D] partial slabs -> their three destinations, one launch
+constexpr int M3L_REDUCE_BATCH_MAX = 56;
+struct ReduceBatchItem {
+    const float* part;
+    float* out[3];
+    int G;
+};
+struct ReduceBatch {
+    ReduceBatchItem it[M3L_REDUCE_BATCH_MAX];
+    int count, D;
+};
+int m3l_reduce_rows_batch(const ReduceBatch* b, int accumulate, hipStream_t st);
+int m3l_ln_bwd_blocks(int M);
 int m3l_reduce_rows_seg3(const float* part, int G, int D, float* out0, float* out1, float* out2, int accumulate, hipStream_t st);
 
 // grouped weight-gradient GEMMs: up to 4 problems dW_i[N_i,K_i] = Y_i^T X_i that share M (one launch + one reduce)

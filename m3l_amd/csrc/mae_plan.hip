@@ -169,6 +169,8 @@ struct TfWs {
     float* dsum;
     float* scratch;
     float* scratch2[2];   // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue (double-buffered like the wgrad operands)
+    float* ln_part;       // [2 depth + 1][ln_part_stride]: dgamma / dbeta / bias-grad partials of every LayerNorm backward, reduced in one launch
+    size_t ln_part_stride;
     size_t scratch_b;
     size_t total;
 };
@@ -214,6 +216,8 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
     for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M, (int)mlp) * mlp);
+    w.ln_part_stride = (size_t)m3l_ln_bwd_blocks((int)M) * 3 * D;
+    w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
     return w;
 }
@@ -516,6 +520,24 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     hipStream_t st = (hipStream_t)stream;
     TfWs w = tf_layout(c, B, n, ws);
     const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
+    // every LayerNorm backward leaves its [G][3 D] partials (dgamma | dbeta | column sums = bias gradient of the Linear that fed the
+    // residual branch) in its own slot; ONE batched reduce at the end of the range, on the side stream, replaces 2 small launches per
+    // layer on the critical path
+    std::vector<ReduceBatch> batches(1);
+    batches[0].count = 0;
+    batches[0].D = D;
+    const int lnG = m3l_ln_bwd_blocks(M);
+    auto ln_slot = [&](int id, float* dgamma, float* dbeta, float* dbias) -> float* {
+        if (batches.back().count == M3L_REDUCE_BATCH_MAX) {
+            batches.emplace_back();
+            batches.back().count = 0;
+            batches.back().D = D;
+        }
+        ReduceBatch& rb = batches.back();
+        float* slot = w.ln_part + (size_t)id * w.ln_part_stride;
+        rb.it[rb.count++] = ReduceBatchItem{slot, {dgamma, dbeta, dbias}, lnG};
+        return slot;
+    };
     const float* x_last = c->depth ? w.L[c->depth - 1].xout : x_in;
     const void* const* tf = tensors + 11 * c->depth;
     float* const* gf = grads + 11 * c->depth;
@@ -524,8 +546,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     if (layer_hi == c->depth) {
         float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;   // fc2 bias of the last layer
         const int top = (c->depth - 1) & 1;
-        if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt, w.scratch,
-                       gf[0], gf[1], db_last, 0, st))
+        if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt,
+                       ln_slot(2 * c->depth, gf[0], gf[1], db_last), nullptr, nullptr, nullptr, 0, st))
             return 1;
     }
     if (side_init()) return 2;
@@ -558,8 +580,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             e.out_t = w.dxn;
             if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;             // dxn2 = du W1
             // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
-            if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt, w.scratch, g[5], g[6],
-                           c->project_out ? g[4] : nullptr, 0, st))
+            if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt,
+                           ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr), nullptr, nullptr, nullptr, 0, st))
                 return 1;
         }
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
@@ -605,10 +627,21 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             e.out_t = w.dxn;
             if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
             if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
-            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt, w.scratch, g[0], g[1],
-                           db_prev, 0, st))
+            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt,
+                           ln_slot(2 * l, g[0], g[1], db_prev), nullptr, nullptr, nullptr, 0, st))
                 return 1;
         }
+    }
+    // the batched LayerNorm-parameter reduce: after the last ln_bwd of the range, on the side stream behind the weight gradients
+    if (batches[0].count > 0) {
+        hipEvent_t ln_ready = side_event();
+        M3L_HIP(hipEventRecord(ln_ready, st));
+        M3L_HIP(hipStreamWaitEvent(s2, ln_ready, 0));
+        for (const ReduceBatch& rb : batches)
+            if (m3l_reduce_rows_batch(&rb, 0, s2)) return 1;
+        hipEvent_t red_done = side_event();
+        M3L_HIP(hipEventRecord(red_done, s2));
+        M3L_HIP(hipStreamWaitEvent(st, red_done, 0));     // also orders every earlier side-stream kernel (the weight gradients)
     }
     // join: every weight gradient is complete before anything later on the caller's stream
     for (int i = 0; i < 2; ++i)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Reproduces the files under profiles/ on a GPU box:   gpurun -- 'bash tools/make_profiles.sh r01'
+# (1) rocprofv3 --kernel-trace --stats over the default bench command; (2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), as
+# the micro-arch guide prescribes; (3) tools/pmc_to_traffic.py condenses them.  The program follows `--` directly (no env / bash -c hop).
+set -e
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/bench.py --no-cpu-baseline --steps 30 --warmup 10 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 2 > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 2 > $OUT/write.log 2>&1
+cd $R
+python3 tools/pmc_to_traffic.py $OUT $TAG
+python3 bench.py > $OUT/final/${TAG}_bench_n1.json 2> $OUT/bench.log
+tail -c 700 $OUT/final/${TAG}_bench_n1.json

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs (tools/make_profiles.sh) into the small files kept under profiles/:
+   <tag>_kernel_stats.csv   the --stats table as rocprofv3 wrote it
+   <tag>_pmc_hbm.csv        per kernel: launches, mean FETCH_SIZE / WRITE_SIZE (KB, raw counters)
+   <tag>_traffic.json       per bench.py kernel class: HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests of 16-byte-per-lane streams are
+tallied as 64 bytes); both counters are in KB.  This is L2-miss traffic and includes Infinity-Cache hits."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(out, "final")
+os.makedirs(dst, exist_ok=True)
+st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+
+def collect(sub, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            a = acc[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return acc
+
+
+fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
+names = sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[1] * 2 + write.get(k, [0, 0])[1]))
+tot = sum((fetch.get(k, [0, 0])[1] * 2 + write.get(k, [0, 0])[1]) for k in names) or 1.0
+with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "launches", "mean_FETCH_SIZE_KB_raw", "mean_WRITE_SIZE_KB_raw", "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024", "share_of_total"])
+    for k in names:
+        nf, sf = fetch.get(k, [0, 0.0])
+        nw, sw = write.get(k, [0, 0.0])
+        w.writerow([k[:120], max(nf, nw, 1), round(sf / max(nf, 1), 1), round(sw / max(nw, 1), 1),
+                    int((2 * sf / max(nf, 1) + sw / max(nw, 1)) * 1024), round((2 * sf + sw) / tot, 4)])
+
+classes = {"gemm_nt_glds64": "gemm_nt_glds_kernel", "gemm_tn": "gemm_tn_glds_kernel", "ln_bwd": "ln_bwd_kernel"}
+traffic = {"_total_bytes_all_kernels_5_steps": int(tot * 1024)}
+for cls, sub in classes.items():
+    nf = sum(v[0] for k, v in fetch.items() if sub in k)
+    sf = sum(v[1] for k, v in fetch.items() if sub in k)
+    nw = sum(v[0] for k, v in write.items() if sub in k)
+    sw = sum(v[1] for k, v in write.items() if sub in k)
+    if nf and nw:
+        traffic[cls] = {"hbm_bytes_per_launch": int((2 * sf / nf + sw / nw) * 1024), "fetch_size_kb": round(sf / nf, 1), "write_size_kb": round(sw / nw, 1),
+                        "launches": nf, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 2 "
+                                                "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md, KB -> bytes x1024; L2-miss traffic incl. Infinity-Cache hits"}
+json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps({k: (v["hbm_bytes_per_launch"] if isinstance(v, dict) else v) for k, v in traffic.items()}))

@@ -169,7 +169,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // and again on the fragment read (guide rule 21) -> conflict-free ds_read_b128.  Two stages; the next K-tile's DMA is
 // issued before the MFMA block of the current one.  Needs K % (128 / sizeof(T)) == 0; rows past M / N are clamped (their
 // products are never stored).
-template <typename T, int BN, int R, int BM = 128>
+// EPI: epilogue specialisation resolved at compile time (0 = generic, every GemmEpi flag tested at run time; the four hot
+// combinations of the transformer get branch-free code the compiler can schedule across the unrolled row segments):
+//   1 FC1    bias + pre-activation copy + GELU -> out_t          2 DGELU  * gelu'(u) -> out_t (+ column-sum partials)
+//   3 PLAIN  (bias) -> out_t                                      4 RES32  bias + fp32 residual -> out_f32
+enum { EPI_GENERIC = 0, EPI_FC1 = 1, EPI_DGELU = 2, EPI_PLAIN = 3, EPI_RES32 = 4 };
+template <typename T, int BN, int R, int BM = 128, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              int M, int N, int K, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -311,8 +316,17 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     T* out_t = reinterpret_cast<T*>(epi.out_t);
     T* out_pre = reinterpret_cast<T*>(epi.out_pre);
     const T* gelu_u = reinterpret_cast<const T*>(epi.gelu_u);
+    constexpr bool GEN = (EPI == EPI_GENERIC);
+    const bool f_gelu_u = GEN ? (gelu_u != nullptr) : (EPI == EPI_DGELU);
+    const bool f_out_pre = GEN ? (out_pre != nullptr) : (EPI == EPI_FC1);
+    const int f_act = GEN ? epi.act : (EPI == EPI_FC1 ? 1 : 0);
+    const bool f_relu_ref = GEN ? (epi.relu_ref != nullptr) : false;
+    const bool f_res = GEN ? (epi.res != nullptr) : (EPI == EPI_RES32);
+    const bool f_out32 = GEN ? (epi.out_f32 != nullptr) : (EPI == EPI_RES32);
+    const bool f_out_t = GEN ? (out_t != nullptr) : (EPI != EPI_RES32);
+    const bool f_colsum = GEN ? (epi.colsum_part != nullptr) : (EPI == EPI_DGELU && epi.colsum_part != nullptr);
     if (col_ok) {
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int rl = r0 + RSTEP * i, row = m0 + rl;
             if (row >= M) break;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
             const long o = (long)row * epi.ldc + col;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * epi.alpha + bias[j];
-            if (gelu_u) {
+            if (f_gelu_u) {
                 Frag<T> uu;
                 if constexpr (sizeof(T) == 2) {
                     uu.v = *reinterpret_cast<const bf16x8*>(gelu_u + o);
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(to_f32(uu.v[j]));
             }
-            if (out_pre) {
+            if (f_out_pre) {
                 Frag<T> pk;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -349,29 +363,29 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
                     for (int j = 0; j < 8; ++j) out_pre[o + j] = pk.v[j];
                 }
             }
-            if (epi.act == 1) {
+            if (f_act == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-            } else if (epi.act == 2) {
+            } else if (f_act == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            if (epi.relu_ref) {
+            if (f_relu_ref) {
                 const T* rr = reinterpret_cast<const T*>(epi.relu_ref);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = to_f32(rr[o + j]) > 0.f ? v[j] : 0.f;
             }
-            if (epi.res) {
+            if (f_res) {
                 const f32x4 q0 = *reinterpret_cast<const f32x4*>(epi.res + o);
                 const f32x4 q1 = *reinterpret_cast<const f32x4*>(epi.res + o + 4);
                 v[0] += q0[0]; v[1] += q0[1]; v[2] += q0[2]; v[3] += q0[3];
                 v[4] += q1[0]; v[5] += q1[1]; v[6] += q1[2]; v[7] += q1[3];
             }
-            if (epi.out_f32) {
+            if (f_out32) {
                 *reinterpret_cast<f32x4*>(epi.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(epi.out_f32 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
-            if (out_t) {
+            if (f_out_t) {
                 Frag<T> pk;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
             }
         }
     }
-    if (epi.colsum_part) {
+    if (f_colsum) {
         // column sums of the compute-type output over this workgroup's rows -> part[blockIdx.y][N] (fixed order)
         float* red = reinterpret_cast<float*>(smem) + BM * CSLD;      // [RSTEP][BN]
 #pragma unroll
@@ -676,10 +690,11 @@ int m3l_gemm_init() {
     if (g_gemm_inited) return 0;
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 128)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16, 64, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 64)));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 64, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, 64)));
+#define NT_ATTR(T, BMv, E) M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<T, 64, 2, BMv, E>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, BMv)))
+#define NT_ATTR5(T, BMv) NT_ATTR(T, BMv, 0); NT_ATTR(T, BMv, 1); NT_ATTR(T, BMv, 2); NT_ATTR(T, BMv, 3); NT_ATTR(T, BMv, 4)
+    NT_ATTR5(bf16, 128); NT_ATTR5(float, 128); NT_ATTR5(bf16, 64); NT_ATTR5(float, 64);
+#undef NT_ATTR5
+#undef NT_ATTR
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
@@ -709,19 +724,34 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     if (K % bke == 0) {
         // 64-wide column tiles, 2-stage ring (48 KiB of LDS -> 3 workgroups per CU: measured faster than deeper rings or wider
         // tiles at 1-2 workgroups per CU); 64-row tiles when 128-row tiles would leave the chip under-filled
-        if (nt_tile_rows(M, N) == 64) {
-            dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 64), 8));
-            if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 64, 2, 64><<<grid, 256, glds_lds_bytes(64, 2, 64), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
-            else
-                gemm_nt_glds_kernel<float, 64, 2, 64><<<grid, 256, glds_lds_bytes(64, 2, 64), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+        const bool plain_alpha = epi->alpha == 1.0f && !epi->relu_ref;
+        int mode = EPI_GENERIC;
+        if (plain_alpha && epi->out_t && epi->out_pre && epi->act == 1 && !epi->gelu_u && !epi->res && !epi->out_f32 && !epi->colsum_part)
+            mode = EPI_FC1;
+        else if (plain_alpha && epi->out_t && epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->out_f32)
+            mode = EPI_DGELU;
+        else if (plain_alpha && epi->out_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->out_f32 && !epi->colsum_part)
+            mode = EPI_PLAIN;
+        else if (plain_alpha && !epi->out_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && epi->res && epi->out_f32 && !epi->colsum_part)
+            mode = EPI_RES32;
+        const bool small = nt_tile_rows(M, N) == 64;
+        const dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, small ? 64 : 128), 8));
+#define NT_LAUNCH(T, BMv, E) gemm_nt_glds_kernel<T, 64, 2, BMv, E><<<grid, 256, glds_lds_bytes(64, 2, BMv), st>>>((const T*)A, lda, (const T*)W, ldw, M, N, K, *epi)
+#define NT_MODES(T, BMv)                                       \
+    switch (mode) {                                            \
+        case EPI_FC1: NT_LAUNCH(T, BMv, EPI_FC1); break;       \
+        case EPI_DGELU: NT_LAUNCH(T, BMv, EPI_DGELU); break;   \
+        case EPI_PLAIN: NT_LAUNCH(T, BMv, EPI_PLAIN); break;   \
+        case EPI_RES32: NT_LAUNCH(T, BMv, EPI_RES32); break;   \
+        default: NT_LAUNCH(T, BMv, EPI_GENERIC); break;        \
+    }
+        if (dtype == 1) {
+            if (small) { NT_MODES(bf16, 64) } else { NT_MODES(bf16, 128) }
         } else {
-            dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, 128), 8));
-            if (dtype == 1)
-                gemm_nt_glds_kernel<bf16, 64, 2, 128><<<grid, 256, glds_lds_bytes(64, 2, 128), st>>>((const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, *epi);
-            else
-                gemm_nt_glds_kernel<float, 64, 2, 128><<<grid, 256, glds_lds_bytes(64, 2, 128), st>>>((const float*)A, lda, (const float*)W, ldw, M, N, K, *epi);
+            if (small) { NT_MODES(float, 64) } else { NT_MODES(float, 128) }
         }
+#undef NT_MODES
+#undef NT_LAUNCH
     } else {
         M3L_CHECK(epi->colsum_part == nullptr, "gemm_nt: colsum epilogue needs K %% %d == 0", bke);
         dim3 grid(cdiv(N, BN), cdiv(M, BM));

@@ -416,92 +416,6 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <typename T> struct TnCfg;
-template <> struct TnCfg<bf16> { static constexpr int BMT = 64, MS = 2, ROW = 144, CPR = 16; };   // 288-byte rows
-template <> struct TnCfg<float> { static constexpr int BMT = 32, MS = 1, ROW = 132, CPR = 32; };  // 528-byte rows
-constexpr int TN_STAGE_BYTES = 18432;               // max(64*288, 32*528)
-constexpr int TN_LDS_BYTES = 4 * TN_STAGE_BYTES;
-
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ Y, int ldy, const T* __restrict__ X, int ldx,
-                                                        int M, int N, int K, int m_per_split, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = TnCfg<T>;
-    constexpr int EPC = Chunk<T>::N;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, sp = blockIdx.z;
-    const int m_beg = sp * m_per_split;
-    const int m_end = min(M, m_beg + m_per_split);
-
-    auto Ys = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st) * TN_STAGE_BYTES); };
-    auto Xs = [&](int st) { return reinterpret_cast<T*>(smem + (2 * st + 1) * TN_STAGE_BYTES); };
-
-    uint4 ry0, ry1, ry2, ry3, rx0, rx1, rx2, rx3;
-    const uint4 zero4 = {0u, 0u, 0u, 0u};
-#define TN_GLOAD1(i, RY, RX, mb)                                                                                              \
-    {                                                                                                                         \
-        const int c = tid + 256 * (i), row = c / C::CPR, cc = c % C::CPR;                                                    \
-        const int m = (mb) + row;                                                                                             \
-        RY = (m < m_end && n0 + cc * EPC < N) ? *reinterpret_cast<const uint4*>(Y + (long)m * ldy + n0 + cc * EPC) : zero4;   \
-        RX = (m < m_end && k0 + cc * EPC < K) ? *reinterpret_cast<const uint4*>(X + (long)m * ldx + k0 + cc * EPC) : zero4;   \
-    }
-#define TN_GLOAD(mb) TN_GLOAD1(0, ry0, rx0, mb) TN_GLOAD1(1, ry1, rx1, mb) TN_GLOAD1(2, ry2, rx2, mb) TN_GLOAD1(3, ry3, rx3, mb)
-#define TN_SWRITE1(i, RY, RX, st)                                                                                             \
-    {                                                                                                                         \
-        const int c = tid + 256 * (i), row = c / C::CPR, cc = c % C::CPR;                                                    \
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Ys(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = RY;         \
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Xs(st)) + row * (C::ROW * (int)sizeof(T)) + cc * 16) = RX;         \
-    }
-#define TN_SWRITE(st) TN_SWRITE1(0, ry0, rx0, st) TN_SWRITE1(1, ry1, rx1, st) TN_SWRITE1(2, ry2, rx2, st) TN_SWRITE1(3, ry3, rx3, st)
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nt = (m_end - m_beg + C::BMT - 1) / C::BMT;
-    if (nt > 0) {
-        TN_GLOAD(m_beg)
-        TN_SWRITE(0)
-    }
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) { TN_GLOAD(m_beg + (t + 1) * C::BMT) }
-#pragma unroll
-        for (int ms = 0; ms < C::MS; ++ms) {
-            Frag<T> fa[4], fb[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                fa[x] = load_ks<KMAP_ACC>(Ys(cur), C::ROW, ms * 32, wr * 64 + x * 16, lane);
-                fb[x] = load_ks<KMAP_ACC>(Xs(cur), C::ROW, ms * 32, wc * 64 + x * 16, lane);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
-        }
-        if (t + 1 < nt) { TN_SWRITE(cur ^ 1) }
-        __syncthreads();
-    }
-#undef TN_GLOAD
-#undef TN_GLOAD1
-#undef TN_SWRITE
-#undef TN_SWRITE1
-    float* P = partial + (long)sp * N * K;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wr * 64 + a * 16 + 4 * g + r, k = k0 + wc * 64 + b * 16 + li;
-                if (n < N && k < K) P[(long)n * K + k] = acc[a][b][r];
-            }
-}
-
 // gemm_tn, main path: both operands arrive by LDS-DMA with hardware bounds checking (buffer_load ... lds: rows past M read
 // as zero, so ragged M needs no tail code), land in unpadded row-major [m][128] tiles whose 16-byte chunk index is XOR-ed
 // with a row-dependent mask on the SOURCE side, and are consumed k-strided: bf16 through ds_read_b64_tr_b16 (the 8 rows a
@@ -697,8 +611,6 @@ int m3l_gemm_init() {
 #undef NT_ATTR
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_gemm_inited = 1;
     return 0;
 }

@@ -116,6 +116,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices, collectives go through gloo):
+    # M3L_BENCH_REHEARSE=1.  Never used for a reported number.
+    rehearse = os.environ.get("M3L_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_comm = os.environ.get("M3L_FORCE_COMM") == "1"       # rehearsal: RCCL calls at world size 1 (one-GPU box)
@@ -125,7 +130,10 @@ def main():
         # RCCL kernels on a high-priority stream: a different hardware-queue pool from the compute stream, so collectives can
         # never be serialised behind compute by HIP's stream -> queue multiplexing
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from m3l_amd import _lib
     from m3l_amd.parallel import FlatAdam, GradSync
@@ -161,7 +169,12 @@ def main():
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        if time.perf_counter() - t_prime > 2.0:
+        done = time.perf_counter() - t_prime > 2.0
+        if dist.is_initialized():                 # every rank must run the SAME number of steps (each step issues collectives)
+            flag = torch.tensor([1.0 if done else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(flag.item() > 0)
+        if done:
             break
     for _ in range(args.warmup):
         step()

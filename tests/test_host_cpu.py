@@ -143,3 +143,27 @@ def test_dinov2_frozen_surface(golden_dir):
         m(torch.zeros(1, 3, 70, 70))
     full = DinoV2Frozen()                                   # dinov2_vits14_reg sizes
     assert sum(p.numel() for p in full.parameters()) == 22_058_112   # == transformers' Dinov2WithRegistersModel at ViT-S/14, 4 registers
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/m3l_amd.h compiles as C99 and as C++11 on its own, and examples/c_host.c — a C program that binds the ABI without any
+    Python — builds against the shared library and reproduces the oracle's mask counts (host-only entry points: no GPU needed)."""
+    import os
+    import subprocess
+    from oracle import vtmae_oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "m3l_amd.h")
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-std=c++11", "-Wall", "-Werror", hdr], check=True)
+    import __graft_entry__ as ge
+    ge.build()
+    libdir = os.path.join(root, "m3l_amd", "lib")
+    exe = str(tmp_path / "c_host")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_host.c"),
+                    "-L" + libdir, "-lm3l_amd", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    nm, nmi, nmt = O.mask_counts(0.75, 64, 128, 2)
+    assert f"cfg2 mask 0.75: masked {nm} unmasked {192 - nm} (image {nmi}, per sensor {nmt})" in out
+    nm, nmi, nmt = O.mask_counts(0.95, 64, 128, 2)
+    assert f"ref  mask 0.95: masked {nm} unmasked {192 - nm} (image {nmi}, per sensor {nmt})" in out
+    assert "error convention:" in out and "must be a multiple" in out

@@ -135,6 +135,7 @@ def test_oracle_vit_tiny_shapes(dt, tol):
     assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"]) and torch.equal(mae.last_mask[1].cpu(), r["unmasked_indices"])
     assert abs(float(loss.detach()) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss.detach()), float(r["loss"]))
     gtol = 2e-3 if dt == "fp32" else 0.15
+    num = den = 0.0
     for name, p in mae.named_parameters():
         ref = P[name].grad
         if ref is None:
@@ -142,6 +143,10 @@ def test_oracle_vit_tiny_shapes(dt, tol):
             continue
         err = float((p.grad.cpu() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
         assert err <= gtol, (name, err)
+        num += float((p.grad.cpu() - ref).double().square().sum())
+        den += float(ref.double().square().sum())
+    # the whole gradient as one vector: relative L2 distance to the fp32 oracle
+    assert (num / den) ** 0.5 <= (1e-4 if dt == "fp32" else 2e-2), (num / den) ** 0.5
 
 
 def test_vision_only_and_use_flags():
@@ -647,3 +652,26 @@ def test_dino_cat_extractor_cfg5():
         ref = ext.mlp.cpu()(torch.cat((pooled, cls), -1))
     ext.mlp.to(DEV)
     assert (out.detach().cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-5
+
+
+_RANDOM_GEOMS = [
+    # (image, ip, tactile, tp, C, k, D, depth, heads, mlp, dd, ddepth, dheads, ratio, B)
+    (32, 8, 16, 4, 3, 1, 64, 1, 1, 72, 64, 1, 1, 0.5, 1),          # one sensor, heads = 1 (identity to_out), mlp not a power of two, B = 1
+    (48, 16, 24, 8, 3, 3, 128, 2, 2, 200, 64, 1, 2, 0.9, 2),       # three sensors, dd < D (truncated decoder sincos), 9 + 3*9 tokens
+    (40, 8, 32, 4, 6, 2, 192, 1, 3, 384, 128, 2, 1, 0.75, 5),      # 25 image + 2*64 tactile tokens, 6 channels, odd batch
+    (28, 14, 28, 14, 3, 2, 64, 2, 2, 128, 64, 1, 2, 0.6, 3),       # 14x14 patches (patch dim 588, K padded), 4 + 2*4 tokens
+    (64, 8, 16, 4, 3, 0, 256, 1, 4, 512, 256, 1, 4, 0.75, 2),      # vision only, D = 256
+    (32, 8, 32, 4, 3, 4, 64, 1, 2, 64, 64, 2, 2, 0.8, 2),          # four sensors (M3L_MAX_SENSORS)
+]
+
+
+@pytest.mark.parametrize("geom", _RANDOM_GEOMS, ids=[f"g{i}" for i in range(len(_RANDOM_GEOMS))])
+def test_assorted_geometries_vs_oracle(geom):
+    """Loss, mask indices and every gradient against the CPU oracle on geometries away from the named configs: B = 1, odd batches,
+    0..4 sensors, token counts that are not multiples of the 16-row MFMA tile, identity to_out, decoder narrower than the encoder."""
+    img, ip, tac, tp, C, k, D, depth, heads, mlp, dd, ddepth, dheads, ratio, B = geom
+    cfg = O.OracleCfg(img, tac, ip, tp, D, depth, heads, mlp, C, k, dd, ddepth, dheads, ratio)
+    _parity_vs_oracle(dict(image_size=img, tactile_size=tac, image_patch_size=ip, tactile_patch_size=tp, dim=D, depth=depth, heads=heads,
+                           mlp_dim=mlp, image_channels=C, tactile_channels=C, num_tactiles=k),
+                      dict(decoder_dim=dd, masking_ratio=ratio, decoder_depth=ddepth, decoder_heads=dheads, num_tactiles=k),
+                      B=B, C=C, hw_img=img, hw_tac=tac, k=k, cfg=cfg, seed=sum(geom[:6]))

@@ -161,6 +161,7 @@ class TransformerFn(torch.autograd.Function):
                                             L.ptr(y_t), L.ptr(y32), _stream()), "m3l_transformer_fwd")
         ctx.saved = (cfg, x, tens, ws)
         ctx.params, ctx.sink = tensors, sink
+        ctx.set_materialize_grads(False)     # an unused output must arrive as None in backward, not as a zero tensor to add and convert
         if y_t is None:
             y_t = y32.clone()     # f32 compute: two distinct autograd outputs over the same values
         return y_t, y32
@@ -169,6 +170,8 @@ class TransformerFn(torch.autograd.Function):
     def backward(ctx, dy_t, dy32):
         cfg, x, tens, ws = ctx.saved
         B, n, D = x.shape
+        if dy_t is None and dy32 is None:         # nothing downstream used this stack
+            return (None, None, None) + (None,) * len(ctx.params)
         if dy_t is not None and dy32 is not None:
             dy, code = (dy32 + dy_t.float()).contiguous(), DT_F32
         elif dy_t is not None:

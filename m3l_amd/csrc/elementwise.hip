@@ -249,9 +249,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, in
                                                        float* __restrict__ part) {
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     for (int c = threadIdx.x; c < N; c += 256) {
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += to_f32(Y[(long)r * ld + c]);
-        part[(long)blockIdx.x * N + c] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent load -> add chains per thread
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += to_f32(Y[(long)r * ld + c]);
+            s1 += to_f32(Y[(long)(r + 1) * ld + c]);
+            s2 += to_f32(Y[(long)(r + 2) * ld + c]);
+            s3 += to_f32(Y[(long)(r + 3) * ld + c]);
+        }
+        for (; r < r1; ++r) s0 += to_f32(Y[(long)r * ld + c]);
+        part[(long)blockIdx.x * N + c] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -508,6 +515,20 @@ __device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, 
     const int c = e % pg.C, p2 = (e / pg.C) % pg.P, p1 = e / (pg.C * pg.P);
     return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
 }
+// The t-th element of a patch in IMAGE order (c, p1, p2 with p2 fastest) and its patch-vector index e.  Kernels that walk a
+// patch with consecutive lanes use this order: P consecutive lanes read P consecutive pixels of one image row (one 4 P-byte
+// segment) instead of 64 lanes touching 64 different (channel, row) places; sums over the patch do not care about the order.
+__device__ __forceinline__ float patch_elem_t(const PatchGroup& pg, int b, int s, int ph, int pw, int t, int& e) {
+    const int pp = pg.P * pg.P;
+    const int c = t / pp, rem = t - c * pp, p1 = rem / pg.P, p2 = rem - p1 * pg.P;
+    e = rem * pg.C + c;
+    return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
+}
+__device__ __forceinline__ int patch_index_t(const PatchGroup& pg, int t) {
+    const int pp = pg.P * pg.P;
+    const int c = t / pp;
+    return (t - c * pp) * pg.C + c;
+}
 
 // gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
 // NV = elements per lane: 16 for patch dims <= 1024, 40 for <= 2560 (cfg 5: 14x14 patches of 4 stacked RGB frames = 2352)
@@ -521,11 +542,13 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     int b, s, ph, pw, local;
     patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
     float v[NV];
+    int ei[NV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int e = lane + 64 * i;
-        v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
+        const int t = lane + 64 * i;
+        ei[i] = t;
+        v[i] = (t < pd) ? patch_elem_t(pg, b, s, ph, pw, t, ei[i]) : 0.f;
         sum += v[i];
     }
     const float mean = wave_sum(sum) / pd;
@@ -539,11 +562,11 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     const float rstd = rsqrtf(wave_sum(q) / pd + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int e = lane + 64 * i;
-        if (e < pd)
+        const int t = lane + 64 * i, e = ei[i];
+        if (t < pd)
             xn[(long)row * pdpad + e] = from_f32<T>((v[i] - mean) * rstd * gamma[e] + beta[e]);
-        else if (e < pdpad)
-            xn[(long)row * pdpad + e] = from_f32<T>(0.f);
+        else if (t < pdpad)
+            xn[(long)row * pdpad + t] = from_f32<T>(0.f);
     }
 }
 
@@ -562,11 +585,13 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         int b, s, ph, pw, local;
         patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
         float v[NV];
+        int ei[NV];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            v[i] = (e < pd) ? patch_elem(pg, b, s, ph, pw, e) : 0.f;
+            const int t = lane + 64 * i;
+            ei[i] = t;
+            v[i] = (t < pd) ? patch_elem_t(pg, b, s, ph, pw, t, ei[i]) : 0.f;
             sum += v[i];
         }
         const float mean = wave_sum(sum) / pd;
@@ -580,9 +605,8 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         const float rstd = rsqrtf(wave_sum(q) / pd + eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            if (e < pd) {
-                const float d = to_f32(dxn[(long)row * pdpad + e]);
+            if (lane + 64 * i < pd) {
+                const float d = to_f32(dxn[(long)row * pdpad + ei[i]]);
                 dg[i] += d * (v[i] - mean) * rstd;
                 db[i] += d;
             }
@@ -596,8 +620,9 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         red[wave][64 + lane] = db[i];
         __syncthreads();
         if (wave == 0) {
-            const int e = lane + 64 * i;
-            if (e < pd) {
+            const int t = lane + 64 * i;
+            if (t < pd) {
+                const int e = patch_index_t(pg, t);
                 out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
                 out[pd + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
             }
@@ -735,33 +760,78 @@ __global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float* __restr
     for (int e = lane; e < dd; e += 64) out[e] = s[e] + dmod[(long)m * dd + e] + prow[e];
 }
 
-// backward: dsrc[b, j] = d_dec_in[b, unmasked[b, j]] ; partials [G][(1 + nmod) * dd]: dmask_token | ddmod[m]
-__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ dY, const int64_t* __restrict__ unmasked,
-                                                              int nvis, const int64_t* __restrict__ masked, int nmask, int B, int dd,
-                                                              int n_img, int n_tac, int nmod, float* __restrict__ dsrc,
-                                                              float* __restrict__ part) {
+// backward of the decoder-input assembly: dsrc[b, j] = dY[b, unmasked[b, j]] ; partials [G][(1 + nmod) * dd]: dmask_token | ddmod[m].
+// Every position of a sample is either visible or masked exactly once, so no index is needed for the sums:
+//   ddmod[m]    = sum of dY over ALL rows whose position belongs to modality m (contiguous position ranges),
+//   dmask_token = (sum over all rows) - (sum over the visible rows).
+// A wave walks a contiguous run of rows with 16-byte loads and keeps running column sums in registers, flushed into its private LDS
+// slab when the modality changes (at most nmod + 1 times per sample); a second loop gathers its share of the visible rows.
+template <int MAXC>
+__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ dY, const int64_t* __restrict__ unmasked, int nvis,
+                                                              int B, int N, int dd, int n_img, int n_tac, int nmod, int rows_per_wave,
+                                                              int vis_per_wave, float* __restrict__ dsrc, float* __restrict__ part) {
     extern __shared__ float sm[];   // [WPB][(1 + nmod) * dd]: one private slab per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int PL = (1 + nmod) * dd;
-    const int N = nvis + nmask;
     for (int i = threadIdx.x; i < WPB * PL; i += 256) sm[i] = 0.f;
     __syncthreads();
     float* my = sm + wave * PL;
-    for (long r = (long)blockIdx.x * WPB + wave; r < (long)B * N; r += (long)gridDim.x * WPB) {
-        const int b = (int)(r / N), j = (int)(r % N);
-        const bool vis = j < nvis;
-        const int pos = (int)(vis ? unmasked[(long)b * nvis + j] : masked[(long)b * nmask + j - nvis]);
+    const long gw = (long)blockIdx.x * WPB + wave;
+    f32x4 acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define UNSH_FLUSH(slot, sign)                                                      \
+    _Pragma("unroll") for (int c = 0; c < MAXC; ++c) {                              \
+        const int e4 = (lane + 64 * c) * 4;                                         \
+        if (e4 < dd) {                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                         \
+                my[e4 + q] += (sign) * acc[c][q];                                   \
+                if ((slot) >= 0) my[(1 + (slot)) * dd + e4 + q] += acc[c][q];       \
+            }                                                                       \
+        }                                                                           \
+        acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
+    }
+    // phase 1: every row of this wave's run, by position
+    const long total = (long)B * N;
+    const long r0 = gw * rows_per_wave, r1 = r0 + rows_per_wave < total ? r0 + rows_per_wave : total;
+    int cur_m = -1;
+    for (long r = r0; r < r1; ++r) {
+        const int pos = (int)(r % N);
         const int m = pos < n_img ? 0 : 1 + (pos - n_img) / n_tac;
-        const float* g = dY + ((long)b * N + pos) * dd;
-        for (int e = lane; e < dd; e += 64) {
-            const float d = g[e];
-            if (vis)
-                dsrc[((long)b * nvis + j) * dd + e] = d;
-            else
-                my[e] += d;
-            my[(1 + m) * dd + e] += d;
+        if (m != cur_m) {
+            if (cur_m >= 0) { UNSH_FLUSH(cur_m, 1.f) }
+            cur_m = m;
+        }
+        const float* g = dY + r * dd;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int e4 = (lane + 64 * c) * 4;
+            if (e4 < dd) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(g + e4);
+                acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
+            }
         }
     }
+    if (cur_m >= 0) { UNSH_FLUSH(cur_m, 1.f) }
+    // phase 2: this wave's share of the visible rows: copy out, and subtract their sum from the mask-token slot
+    const long vtotal = (long)B * nvis;
+    const long v0 = gw * vis_per_wave, v1 = v0 + vis_per_wave < vtotal ? v0 + vis_per_wave : vtotal;
+    for (long v = v0; v < v1; ++v) {
+        const int b = (int)(v / nvis);
+        const int pos = (int)unmasked[v];
+        const float* g = dY + ((long)b * N + pos) * dd;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int e4 = (lane + 64 * c) * 4;
+            if (e4 < dd) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(g + e4);
+                *reinterpret_cast<f32x4*>(dsrc + v * dd + e4) = d;
+                acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
+            }
+        }
+    }
+    { UNSH_FLUSH(-1, -1.f) }
+#undef UNSH_FLUSH
     __syncthreads();
     for (int i = threadIdx.x; i < PL; i += 256)
         part[(long)blockIdx.x * PL + i] = sm[i] + sm[PL + i] + sm[2 * PL + i] + sm[3 * PL + i];
@@ -804,12 +874,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         int b, s, ph, pw, local;
         patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-        for (int e = lane; e < pdpad; e += 64) {
+        for (int t = lane; t < pdpad; t += 64) {
             float d = 0.f;
-            if (e < pd) {
-                const float t = patch_elem(pg, b, s, ph, pw, e);
-                d = pred[(long)row * pdpad + e] - t;
-                if (target_out) target_out[(long)row * pd + e] = t;
+            int e = t;
+            if (t < pd) {
+                const float tv = patch_elem_t(pg, b, s, ph, pw, t, e);
+                d = pred[(long)row * pdpad + e] - tv;
+                if (target_out) target_out[(long)row * pd + e] = tv;
             }
             acc += d * d;
             dpred[(long)row * pdpad + e] = from_f32<T>(2.f * w * d);
@@ -1141,9 +1212,20 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
                       hipStream_t st) {
     const long rows = (long)B * (nvis + nmask);
     const int PL = (1 + nmod) * dd;
-    const int G = part_grid(rows);
-    unshuffle_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dY, unmasked, nvis, masked, nmask, B, dd, n_img, n_tac > 0 ? n_tac : 1,
-                                                             nmod, dsrc, part_ws);
+    M3L_CHECK(dd % 4 == 0 && dd <= 1024, "unshuffle_bwd: dd=%d must be a multiple of 4, <= 1024", dd);
+    (void)masked;
+    int rpw = 16;                                       // rows per wave; fewer waves than M3L_MAX_PARTIAL_BLOCKS workgroups
+    while (cdiv(cdiv(rows, rpw), WPB) > M3L_MAX_PARTIAL_BLOCKS) rpw *= 2;
+    const int G = cdiv(cdiv(rows, rpw), WPB);
+    const int vpw = cdiv((long)B * nvis, (long)G * WPB);
+    const int N = nvis + nmask, nt = n_tac > 0 ? n_tac : 1;
+    const size_t lds = WPB * PL * sizeof(float);
+    if (dd <= 256)
+        unshuffle_bwd_kernel<1><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
+    else if (dd <= 512)
+        unshuffle_bwd_kernel<2><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
+    else
+        unshuffle_bwd_kernel<4><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
     M3L_LAUNCH_CHECK();
     reduce_rows_kernel<<<cdiv(dd, 32), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
     reduce_rows_kernel<<<cdiv(nmod * dd, 32), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);

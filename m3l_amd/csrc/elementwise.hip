@@ -1160,8 +1160,8 @@ int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int id
     }
 #undef PATCH_LN_BWD
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws, G, 2 * pd, pd, dgamma, accumulate);
-    reduce_rows_kernel<<<cdiv(pd, 32), 256, 0, st>>>(part_ws + pd, G, 2 * pd, pd, dbeta, accumulate);
+    ReduceSegs segs = {{dgamma, dbeta, nullptr, nullptr}};      // both halves of the [G][2 pd] slab in one launch
+    reduce_rows_seg_kernel<<<dim3(cdiv(pd, 32), 2), 1024, 0, st>>>(part_ws, G, 2 * pd, pd, segs, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1227,8 +1227,13 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
     else
         unshuffle_bwd_kernel<4><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(dd, 32), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
-    reduce_rows_kernel<<<cdiv(nmod * dd, 32), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
+    if (nmod <= 3) {                                            // mask token + every modality row: equal-width segments, one launch
+        ReduceSegs segs = {{dmask_token, ddmod, nmod > 1 ? ddmod + dd : nullptr, nmod > 2 ? ddmod + 2 * dd : nullptr}};
+        reduce_rows_seg_kernel<<<dim3(cdiv(dd, 32), 1 + nmod), 1024, 0, st>>>(part_ws, G, PL, dd, segs, accumulate);
+    } else {
+        reduce_rows_kernel<<<cdiv(dd, 32), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
+        reduce_rows_kernel<<<cdiv(nmod * dd, 32), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
+    }
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -349,6 +349,21 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
     const float* mod = (const float*)tensors[12];
     const float* pos[2] = {(const float*)tensors[13], (const float*)tensors[14]};
     const int mod0[2] = {0, 1};
+    if (!backward) {
+        // compute-type weight copies of both groups (zero-padded K) in ONE launch; pad columns must be zero (nothing to clear
+        // when there is no padding)
+        WeightPack pk;
+        memset(&pk, 0, sizeof(pk));
+        for (int i = 0; i < 2; ++i) {
+            if (cnt[i] == 0) continue;
+            if (pdp[i] != pd[i]) {
+                M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)D * pdp[i] * esz(dtype), st));
+                M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)pdp[i] * D * esz(dtype), st));
+            }
+            pk.d[pk.count++] = WeightDesc{(const float*)tensors[6 * i + 2], w.g[i].w, w.g[i].wT, D, pd[i], pdp[i], D};
+        }
+        if (m3l_prep_weights(dtype, &pk, st)) return 1;
+    }
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
@@ -356,14 +371,6 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
         const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *W = (const float*)t[2], *bias = (const float*)t[3];
         const float *ln2_w = (const float*)t[4], *ln2_b = (const float*)t[5];
         if (!backward) {
-            // compute-type weight copies (zero-padded K) — pad columns must be zero
-            M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)D * pdp[i] * esz(dtype), st));
-            M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)pdp[i] * D * esz(dtype), st));
-            WeightPack pk;
-            memset(&pk, 0, sizeof(pk));
-            pk.d[0] = WeightDesc{W, w.g[i].w, w.g[i].wT, D, pd[i], pdp[i], D};
-            pk.count = 1;
-            if (m3l_prep_weights(dtype, &pk, st)) return 1;
             if (m3l_patch_ln(dtype, &pgs[i], idx, L, j0[i], cnt[i], B, ln1_w, ln1_b, LN_EPS, w.g[i].xn, pdp[i], st)) return 1;
             GemmEpi e = epi0(D);
             e.bias = bias;
@@ -868,16 +875,22 @@ int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int 
     float* pred_out[2] = {pred_img, pred_tac};
     int nparts = 0;
     int part_beg[2] = {0, 0}, part_cnt[2] = {0, 0};
+    {
+        WeightPack pk;                       // both heads' compute-type weight copies in one launch
+        memset(&pk, 0, sizeof(pk));
+        for (int i = 0; i < 2; ++i) {
+            if (cnt[i] == 0) continue;
+            if (pdp[i] != pd[i]) {
+                M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)pdp[i] * dd * esz(dtype), st));
+                M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)dd * pdp[i] * esz(dtype), st));
+            }
+            pk.d[pk.count++] = WeightDesc{(const float*)tensors[2 * i], w.g[i].w, w.g[i].wT, pd[i], dd, dd, pdp[i]};
+        }
+        if (m3l_prep_weights(dtype, &pk, st)) return 1;
+    }
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
-        M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)pdp[i] * dd * esz(dtype), st));
-        M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)dd * pdp[i] * esz(dtype), st));
-        WeightPack pk;
-        memset(&pk, 0, sizeof(pk));
-        pk.d[0] = WeightDesc{(const float*)tensors[2 * i], w.g[i].w, w.g[i].wT, pd[i], dd, dd, pdp[i]};
-        pk.count = 1;
-        if (m3l_prep_weights(dtype, &pk, st)) return 1;
         if (m3l_gather_rows(dtype, dec_t, N, dd, masked, nmask, j0[i], cnt[i], B, w.g[i].dg, st)) return 1;
         GemmEpi e = epi0(pdp[i]);
         e.bias = (const float*)tensors[2 * i + 1];
@@ -1010,8 +1023,10 @@ int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* 
     CnnWs w = cnn_layout(c, Btot, ws);
     for (int l = 0; l < 4; ++l) {
         const ConvL& L = w.L[l];
-        M3L_HIP(hipMemsetAsync(w.w[l], 0, (size_t)L.Co * L.Kpad * esz(dt), st));
-        M3L_HIP(hipMemsetAsync(w.wT[l], 0, (size_t)L.Kpad * L.Co * esz(dt), st));
+        if (L.Kpad != L.K) {
+            M3L_HIP(hipMemsetAsync(w.w[l], 0, (size_t)L.Co * L.Kpad * esz(dt), st));
+            M3L_HIP(hipMemsetAsync(w.wT[l], 0, (size_t)L.Kpad * L.Co * esz(dt), st));
+        }
         WeightPack pk;
         memset(&pk, 0, sizeof(pk));
         pk.d[0] = WeightDesc{(const float*)tensors[2 * l], w.w[l], w.wT[l], L.Co, L.K, L.Kpad, L.Co};

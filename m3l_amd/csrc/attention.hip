@@ -31,6 +31,16 @@ __device__ __forceinline__ void stage_tile(T* dst, const T* src, long ld, int r0
     }
 }
 
+// 4 consecutive columns of one output row as ONE store (8 bytes of bf16 / 16 bytes of f32).  The transposed accumulator layout puts
+// consecutive lanes on consecutive ROWS, so every store instruction scatters over 16 rows; four scalar 2-byte stores per
+// (lane, 16-column tile) quadruple the number of write requests for nothing.
+__device__ __forceinline__ void store4(bf16* p, f32x4 v) {
+    bf16x4 pk;
+    pk[0] = (bf16)v[0]; pk[1] = (bf16)v[1]; pk[2] = (bf16)v[2]; pk[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = pk;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                          int n, int H, float scale) {
@@ -110,9 +120,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         const float inv = 1.0f / lsum;
         T* orow = o + ((long)b * n + q) * ldo + hh * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) orow[16 * d + 4 * g + r] = from_f32<T>(oacc[d][r] * inv);
+        for (int d = 0; d < 4; ++d) store4(orow + 16 * d + 4 * g, oacc[d] * inv);
         if (g == 0) lse[((long)b * H + hh) * n + q] = m + __logf(lsum);
     }
 }
@@ -189,9 +197,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     if (q < n) {
         T* row = dqkv + ((long)b * n + q) * ld + hh * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) row[16 * d + 4 * g + r] = from_f32<T>(dq[d][r]);
+        for (int d = 0; d < 4; ++d) store4(row + 16 * d + 4 * g, dq[d]);
     }
 }
 
@@ -269,12 +275,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         T* krow = dqkv + ((long)b * n + key) * ld + H * 64 + hh * 64;
         T* vrow = krow + H * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                krow[16 * d + 4 * g + r] = from_f32<T>(dk[d][r]);
-                vrow[16 * d + 4 * g + r] = from_f32<T>(dv[d][r]);
-            }
+        for (int d = 0; d < 4; ++d) {
+            store4(krow + 16 * d + 4 * g, dk[d]);
+            store4(vrow + 16 * d + 4 * g, dv[d]);
+        }
     }
 }
 

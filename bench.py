@@ -50,6 +50,17 @@ def fwd_flops_per_sample(c):
     return embed + tf(nvis, c["dim"], c["depth"], c["heads"], c["mlp_dim"]) + tf(N, c["dec_dim"], c["dec_depth"], c["dec_heads"], 4 * c["dec_dim"]) + heads
 
 
+def attn_gemm_fwd_flops_per_sample(c):
+    """QK^T + AV of every layer, forward (4 n^2 h d_h per layer)."""
+    n_img, n_tac = (c["image_size"] // c["image_patch_size"]) ** 2, (c["tactile_size"] // c["tactile_patch_size"]) ** 2
+    k = c["num_tactiles"]
+    N = n_img + k * n_tac
+    nmask = int(c["ratio"] * N)
+    nm_img = int(nmask * (n_img / N))
+    nvis = N - nm_img - k * ((nmask - nm_img) // k)
+    return c["depth"] * 4 * nvis * nvis * c["heads"] * 64 + c["dec_depth"] * 4 * N * N * c["dec_heads"] * 64
+
+
 def build_model(c, dtype, device):
     from m3l_amd import VTMAE, VTT
     torch.manual_seed(0)
@@ -241,6 +252,10 @@ def main():
                                "mfma_tflops": round(work / launches / avg_s / 1e12, 1), "mfma_frac_of_2500": round(work / launches / avg_s / 2.5e15, 4)}
         total_flops = 3 * fwd_flops_per_sample(c) * value
         out["model_tflops"] = round(total_flops / 1e12, 2)
+        # BASELINE north_star: throughput also "as fraction of the attention-GEMM roofline" = QK^T + AV FLOPs (fwd + bwd = 3x fwd,
+        # SURVEY 8d) at this sample rate over the dense bf16 MFMA peak of the GPUs used
+        attn = 3 * attn_gemm_fwd_flops_per_sample(c) * value
+        out["attention_gemm"] = {"tflops": round(attn / 1e12, 2), "frac_of_bf16_peak": round(attn / (world * PEAK_BF16_TFLOPS * 1e12), 5)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

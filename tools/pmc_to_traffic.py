@@ -45,6 +45,21 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
         w.writerow([k[:120], max(nf, nw, 1), round(sf / max(nf, 1), 1), round(sw / max(nw, 1), 1),
                     int((2 * sf / max(nf, 1) + sw / max(nw, 1)) * 1024), round((2 * sf + sw) / tot, 4)])
 
+# MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is
+# summed over the 8 XCDs)
+busy, active = collect("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), collect("mfma", "GRBM_GUI_ACTIVE")
+if busy and active:
+    with open(os.path.join(dst, f"{tag}_mfma_util.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "launches", "avg_kernel_cycles(GRBM_GUI_ACTIVE/8)", "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES/(cycles*1024 SIMDs)"])
+        for k in sorted(busy, key=lambda k: -busy[k][1]):
+            n, sb = busy[k]
+            na, sa = active.get(k, [0, 0.0])
+            if not na or sa <= 0:
+                continue
+            cyc = sa / na / 8.0
+            w.writerow([k[:110], n, int(cyc), round((sb / n) / (cyc * 1024.0), 4)])
+
 classes = {"gemm_nt_glds64": "gemm_nt_glds_kernel", "gemm_tn": "gemm_tn_glds_kernel", "ln_bwd": "ln_bwd_kernel"}
 traffic = {"_total_bytes_all_kernels_5_steps": int(tot * 1024)}
 for cls, sub in classes.items():

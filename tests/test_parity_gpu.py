@@ -675,3 +675,47 @@ def test_assorted_geometries_vs_oracle(geom):
                            mlp_dim=mlp, image_channels=C, tactile_channels=C, num_tactiles=k),
                       dict(decoder_dim=dd, masking_ratio=ratio, decoder_depth=ddepth, decoder_heads=dheads, num_tactiles=k),
                       B=B, C=C, hw_img=img, hw_tac=tac, k=k, cfg=cfg, seed=sum(geom[:6]))
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """state_dict() / load_state_dict() of the module and of FlatAdam after the parameters were re-homed into GradSync's flat buffer:
+    2 steps + save + fresh objects + load + 2 steps == 4 uninterrupted steps, bit for bit (SB3 zip checkpoints, utils/callbacks.py:126-133)."""
+    import copy
+    from m3l_amd.parallel import FlatAdam, GradSync
+
+    def make():
+        torch.manual_seed(0)
+        enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128)
+        mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, compute_dtype="bf16").to(DEV)
+        sync = GradSync(mae)
+        return mae, sync, FlatAdam(sync, lr=1e-3, weight_decay=0.01)
+
+    def batch(i):
+        g = torch.Generator().manual_seed(50 + i)
+        x = {"image": torch.rand(4, 3, 32, 32, generator=g).to(DEV), "tactile1": torch.rand(4, 3, 16, 16, generator=g).to(DEV),
+             "tactile2": torch.rand(4, 3, 16, 16, generator=g).to(DEV)}
+        return x, [torch.rand(4, 16, generator=g).to(DEV) for _ in range(3)]
+
+    def steps(mae, sync, opt, idx):
+        for i in idx:
+            x, noises = batch(i)
+            sync.zero_grad()
+            mae(x, mask_noise=noises).backward()
+            sync.finish()
+            opt.step()
+
+    a = make()
+    steps(*a, range(4))
+    b = make()
+    steps(*b, range(2))
+    ck_model = copy.deepcopy({k: v.cpu() for k, v in b[0].state_dict().items()})
+    ck_opt = {k: (v.cpu().clone() if torch.is_tensor(v) else copy.deepcopy(v)) for k, v in b[2].state_dict().items() if k != "param_groups"}
+    c = make()
+    c[0].load_state_dict(ck_model, strict=True)
+    assert c[0].mask_token.data_ptr() == dict(c[0].named_parameters())["mask_token"].data_ptr()
+    c[2].load_state_dict({"step": ck_opt["step"], "exp_avg": ck_opt["exp_avg"].to(DEV), "exp_avg_sq": ck_opt["exp_avg_sq"].to(DEV)})
+    steps(*c, range(2, 4))
+    torch.cuda.synchronize()
+    assert torch.equal(a[1].flat_params, c[1].flat_params)
+    for (k, v), (_, w) in zip(a[0].state_dict().items(), c[0].state_dict().items()):
+        assert torch.equal(v, w), k

@@ -214,6 +214,48 @@ def run_reconstruct(ref, name, *, early_conv, ratio, mask_ratio, seed, use_tacti
     print(f"{name}: keys={sorted(r.keys())} losses={[float(v) for k, v in r.items() if k.startswith('recon_loss')]}")
 
 
+def run_ppo_like(ref):
+    """The MAE update of `PPO_MAE.train` (models/ppo_mae.py:232-266) with a separate optimizer: frame-stacked rollout observations
+    -> permute / reshape -> vt_load -> mae(x) -> backward -> Adam(lr).step(), two mini-batches.  Records the losses and the weights
+    after each step, so a replacement is pinned through the optimizer as well."""
+    import utils.pretrain_utils as pu
+    torch.manual_seed(61)
+    fs, B, nb = 2, 3, 2
+    enc = ref.VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+                  image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = ref.VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2,
+                    early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=fs)
+    mae.train()
+    opt = torch.optim.Adam(mae.parameters(), lr=1e-3)                       # ppo_mae.py:182-183 (lr raised so two steps are visible)
+    g = torch.Generator().manual_seed(62)
+    obs = {"image": torch.rand(B * nb, fs, 32, 32, 3, generator=g), "tactile": torch.rand(B * nb, fs, 6, 16, 16, generator=g) * 2 - 1}
+    out = {"param0/" + k: v.detach().clone().numpy() for k, v in mae.state_dict().items()}
+    out["obs/image"], out["obs/tactile"] = obs["image"].numpy(), obs["tactile"].numpy()
+    o = {k: v.clone() for k, v in obs.items()}
+    o["image"] = o["image"].permute(0, 2, 3, 1, 4)
+    o["image"] = o["image"].reshape((o["image"].shape[0], o["image"].shape[1], o["image"].shape[2], -1))
+    o["tactile"] = o["tactile"].reshape((o["tactile"].shape[0], -1, o["tactile"].shape[3], o["tactile"].shape[4]))
+    losses = []
+    for i in range(nb):
+        opt.zero_grad()
+        x = pu.vt_load({k: v[i * B:(i + 1) * B].clone() for k, v in o.items()}, frame_stack=fs)
+        noises = [_noise(g, B, 16) for _ in range(3)]
+        for j, nz in enumerate(noises):
+            out[f"noise/{i}/{j}"] = nz.numpy()
+        with _RandQueue(noises):
+            loss = mae(x)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        for k in ("to_pixels.weight", "encoder.transformer.layers.0.0.to_qkv.weight", "mask_token", "encoder.image_to_patch_embedding.2.bias"):
+            out[f"step{i}/" + k] = dict(mae.named_parameters())[k].detach().clone().numpy()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["meta"] = np.array([32, 16, 8, 4, 64, 1, 2, 128, 3 * fs, 2, 64, 1, 2, B], dtype=np.int64)
+    out["frame_stack"] = np.array(fs)
+    np.savez_compressed(os.path.join(HERE, "ppo_like_step.npz"), **out)
+    print("ppo_like_step: losses", losses)
+
+
 def run_vt_load(ref):
     import utils.pretrain_utils as pu  # the reference's own file (cv2 / SB3 logger stubbed)
     g = np.random.default_rng(7)
@@ -274,8 +316,12 @@ def run_vtt_dino():
 
 def main():
     ref = _load_reference()
+    if "--ppo-only" in sys.argv:
+        run_ppo_like(ref)
+        return
     if "--reconstruct-only" not in sys.argv:
         _main_cases(ref)
+        run_ppo_like(ref)
     # F: reconstruct(): count rule int(r*n) (0.7*16 -> 11 image, 11 per sensor), both masking modes, default + vision-only
     run_reconstruct(ref, "recon_small", early_conv=False, ratio=0.75, mask_ratio=0.7, seed=31)
     run_reconstruct(ref, "recon_default_ratio", early_conv=False, ratio=0.8, mask_ratio=None, seed=32, use_tactile=False)

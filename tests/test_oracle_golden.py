@@ -194,3 +194,27 @@ def test_dinov2_oracle_vs_independent_implementation(golden_dir):
     np.testing.assert_allclose(r["tokens_in"].numpy(), z["out/tokens_in"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r["x_norm"].numpy(), z["out/x_norm"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(r["cls"].numpy(), z["out/cls"], rtol=1e-4, atol=1e-5)
+
+
+def test_ppo_like_update_with_adam(golden_dir):
+    """The reference's MAE update as PPO_MAE.train runs it (models/ppo_mae.py:232-266: reshape frame-stacked observations -> vt_load ->
+    loss -> backward -> Adam.step), two mini-batches: the oracle + torch.optim.Adam reproduce both losses and the stepped weights."""
+    z = _load(golden_dir, "ppo_like_step")
+    fs = int(z["frame_stack"])
+    cfg = O.cfg_from_meta(z["meta"], 0.75)
+    P = {k[len("param0/"):]: torch.tensor(z[k]).clone().requires_grad_(torch.tensor(z[k]).dtype.is_floating_point)
+         for k in z.files if k.startswith("param0/")}
+    trainable = [k for k, v in P.items() if v.requires_grad and not k.endswith("pos_embedding") and "pos_emb" not in k]
+    opt = torch.optim.Adam([P[k] for k in trainable], lr=1e-3)
+    img = z["obs/image"].transpose(0, 2, 3, 1, 4).reshape(6, 32, 32, -1)
+    tac = z["obs/tactile"].reshape(6, -1, 16, 16)
+    for i in range(2):
+        opt.zero_grad()
+        x = O.vt_load({"image": img[3 * i:3 * i + 3], "tactile": tac[3 * i:3 * i + 3]}, frame_stack=fs)
+        noises = [torch.tensor(z[f"noise/{i}/{j}"]) for j in range(3)]
+        loss = O.vtmae_forward(P, cfg, x, noises)["loss"]
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - float(z["losses"][i])) <= 2e-5 * float(z["losses"][i])
+        for k in [f[len(f"step{i}/"):] for f in z.files if f.startswith(f"step{i}/")]:
+            np.testing.assert_allclose(P[k].detach().numpy(), z[f"step{i}/{k}"], rtol=2e-4, atol=2e-6, err_msg=k)

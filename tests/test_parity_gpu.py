@@ -719,3 +719,39 @@ def test_checkpoint_resume_is_bit_identical():
     assert torch.equal(a[1].flat_params, c[1].flat_params)
     for (k, v), (_, w) in zip(a[0].state_dict().items(), c[0].state_dict().items()):
         assert torch.equal(v, w), k
+
+
+@pytest.mark.parametrize("optimizer", ["torch_adam", "flat_adam"])
+def test_ppo_like_update_golden(golden_dir, optimizer):
+    """The whole MAE update of PPO_MAE.train (models/ppo_mae.py:232-266) against the reference's own run, THROUGH THE OPTIMIZER:
+    frame-stacked observations -> m3l_amd.vt_load -> VTMAE -> backward -> Adam step, two mini-batches; losses and stepped weights."""
+    from m3l_amd import vt_load
+    from m3l_amd.parallel import FlatAdam, GradSync
+    z = np.load(os.path.join(golden_dir, "ppo_like_step.npz"))
+    fs = int(z["frame_stack"])
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=fs)
+    mae.load_state_dict({k[len("param0/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param0/")}, strict=True)
+    mae = mae.to(DEV).train()
+    if optimizer == "flat_adam":
+        sync = GradSync(mae)
+        opt = FlatAdam(sync, lr=1e-3)
+    else:
+        sync = None
+        opt = torch.optim.Adam(mae.parameters(), lr=1e-3)
+    obs = {"image": torch.tensor(z["obs/image"]), "tactile": torch.tensor(z["obs/tactile"])}
+    o = {"image": obs["image"].permute(0, 2, 3, 1, 4).reshape(6, 32, 32, -1), "tactile": obs["tactile"].reshape(6, -1, 16, 16)}
+    for i in range(2):
+        opt.zero_grad()
+        x = vt_load({k: v[3 * i:3 * i + 3].numpy() for k, v in o.items()}, frame_stack=fs, device=DEV)
+        noises = [torch.tensor(z[f"noise/{i}/{j}"]).to(DEV) for j in range(3)]
+        loss = mae(x, mask_noise=noises)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        assert abs(float(loss.detach()) - float(z["losses"][i])) <= 1e-4 * float(z["losses"][i])
+        named = dict(mae.named_parameters())
+        for k in [f[len(f"step{i}/"):] for f in z.files if f.startswith(f"step{i}/")]:
+            np.testing.assert_allclose(named[k].detach().cpu().numpy(), z[f"step{i}/{k}"], rtol=1e-3, atol=1e-5, err_msg=k)

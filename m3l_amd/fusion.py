@@ -22,6 +22,41 @@ from .pretrain_models import VTT
 from .pretrain_utils import vt_load
 
 
+def _flatten_frame_stack(observations):
+    """(B, fs, H, W, 3) -> (B, H, W, 3*fs) and (B, fs, 6, h, w) -> (B, 6*fs, h, w), as both reference extractors do before vt_load."""
+    obs = dict(observations)
+    if "image" in obs and len(obs["image"].shape) == 5:
+        im = obs["image"].permute(0, 2, 3, 1, 4)
+        obs["image"] = im.reshape(im.shape[0], im.shape[1], im.shape[2], -1)
+    if "tactile" in obs and len(obs["tactile"].shape) == 5:
+        t = obs["tactile"]
+        obs["tactile"] = t.reshape(t.shape[0], -1, t.shape[3], t.shape[4])
+    return obs
+
+
+class MAEExtractor(nn.Module):
+    """Policy-side consumer of the MAE (reference `MAEExtractor`, models/pretrain_models.py:788-841): observations -> vt_load ->
+    `mae_model.get_embeddings(eval=False)` -> 1-layer Transformer (`vit_layer.transformer`) -> mean over tokens -> (B, dim_embeddings).
+    Same constructor arguments after `observation_space`, same sub-module names; a plain nn.Module (SB3 is not part of this package)."""
+
+    def __init__(self, mae_model, dim_embeddings, vision_only_control, frame_stack, observation_space=None):
+        super().__init__()
+        self.features_dim = dim_embeddings
+        self.flatten = nn.Flatten()
+        self.mae_model = mae_model
+        self.running_buffer = {}
+        self.vision_only_control = vision_only_control
+        self.frame_stack = frame_stack
+        self.vit_layer = VTT(image_size=(64, 64), tactile_size=(32, 32), image_patch_size=8, tactile_patch_size=4,    # sizes unused:
+                             dim=dim_embeddings, depth=1, heads=4, mlp_dim=dim_embeddings * 2, num_tactiles=2)       # only .transformer runs
+
+    def forward(self, observations):
+        dev = self.vit_layer.pos_embedding.device
+        vt = vt_load(_flatten_frame_stack(observations), frame_stack=self.frame_stack, device=dev)
+        tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
+        return self.flatten(torch.mean(self.vit_layer.transformer(tokens), dim=1))
+
+
 class DinoCatMAEExtractor(nn.Module):
     def __init__(self, dino_model, mae_model, dim_embeddings, vision_only_control, frame_stack, observation_space=None):
         super().__init__()
@@ -49,15 +84,8 @@ class DinoCatMAEExtractor(nn.Module):
         return image[:, lo:lo + 3]
 
     def forward(self, observations):
-        obs = dict(observations)
-        if "image" in obs and len(obs["image"].shape) == 5:          # (B, fs, H, W, 3) -> (B, H, W, 3*fs)
-            im = obs["image"].permute(0, 2, 3, 1, 4)
-            obs["image"] = im.reshape(im.shape[0], im.shape[1], im.shape[2], -1)
-        if "tactile" in obs and len(obs["tactile"].shape) == 5:      # (B, fs, 6, h, w) -> (B, 6*fs, h, w)
-            t = obs["tactile"]
-            obs["tactile"] = t.reshape(t.shape[0], -1, t.shape[3], t.shape[4])
         dev = self.query.device
-        vt = vt_load(obs, frame_stack=self.frame_stack, device=dev)
+        vt = vt_load(_flatten_frame_stack(observations), frame_stack=self.frame_stack, device=dev)
         tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
         dino = self.dino_model(self.middle_frame(vt["image"]))
         pooled = torch.mean(self.vit_layer.transformer(tokens), dim=1)

@@ -44,6 +44,11 @@ def _install_stubs():
         def __init__(self, *a, **k):
             pass
 
+    class _BFE(torch.nn.Module):  # stable_baselines3 BaseFeaturesExtractor: an nn.Module that remembers features_dim
+        def __init__(self, observation_space=None, features_dim=0):
+            super().__init__()
+            self._features_dim = features_dim
+
     vp = mod("vit_pytorch")
     vp.vit = mod("vit_pytorch.vit", pair=tp.pair, Transformer=tp.Transformer)
     pe = mod("positional_encodings")
@@ -52,7 +57,7 @@ def _install_stubs():
     gym.spaces = mod("gymnasium.spaces", Space=_Dummy, Dict=_Dummy, Box=_Dummy)
     sb3 = mod("stable_baselines3")
     sb3.common = mod("stable_baselines3.common")
-    mod("stable_baselines3.common.torch_layers", BaseFeaturesExtractor=torch.nn.Module, FlattenExtractor=_Dummy)
+    mod("stable_baselines3.common.torch_layers", BaseFeaturesExtractor=_BFE, FlattenExtractor=_Dummy)
     mod("stable_baselines3.common.type_aliases", Schedule=object)
     mod("stable_baselines3.common.policies", ActorCriticPolicy=torch.nn.Module)
     mod("stable_baselines3.common.logger", Video=_Dummy)
@@ -256,6 +261,40 @@ def run_ppo_like(ref):
     print("ppo_like_step: losses", losses)
 
 
+def run_extractor(ref):
+    """`MAEExtractor.forward` (models/pretrain_models.py:788-841), the policy-side consumer: frame-stacked observations -> vt_load ->
+    get_embeddings(eval=False) -> 1-layer Transformer -> mean over tokens.  The SB3 base class is an inert nn.Module stub."""
+    torch.manual_seed(71)
+    fs, B, D = 2, 3, 64
+    enc = ref.VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=D, depth=2, heads=2, mlp_dim=128,
+                  image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = ref.VTMAE(encoder=enc, decoder_dim=D, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2,
+                    early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=fs)
+    g = torch.Generator().manual_seed(72)
+    out = {}
+    for vision_only in (False, True):
+        ext = ref.MAEExtractor(None, mae, D, vision_only, fs)
+        with torch.no_grad():
+            for n_, p in ext.vit_layer.named_parameters():       # (the MAE is shared by both extractors: leave it alone)
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+        obs = {"image": torch.rand(B, fs, 32, 32, 3, generator=g), "tactile": torch.rand(B, fs, 6, 16, 16, generator=g) * 2 - 1}
+        tag = "vision_only" if vision_only else "vt"
+        out[f"{tag}/obs/image"], out[f"{tag}/obs/tactile"] = obs["image"].numpy().copy(), obs["tactile"].numpy().copy()
+        feat = ext({k: v.clone() for k, v in obs.items()})
+        feat.square().mean().backward()
+        out[f"{tag}/features"] = feat.detach().numpy()
+        out[f"{tag}/grad/mae.encoder.transformer.layers.0.0.to_qkv.weight"] = mae.encoder.transformer.layers[0][0].to_qkv.weight.grad.clone().numpy()
+        out[f"{tag}/grad/vit_layer.transformer.layers.0.1.net.1.weight"] = ext.vit_layer.transformer.layers[0][1].net[1].weight.grad.clone().numpy()
+        out.update({f"{tag}/param/vit_layer." + k: v.detach().clone().numpy() for k, v in ext.vit_layer.state_dict().items() if k.startswith("transformer.")})
+        mae.zero_grad()
+    out.update({"param/mae." + k: v.detach().clone().numpy() for k, v in mae.state_dict().items()})
+    out["meta"] = np.array([32, 16, 8, 4, D, 2, 2, 128, 3 * fs, 2, D, 1, 2, B], dtype=np.int64)
+    out["frame_stack"] = np.array(fs)
+    np.savez_compressed(os.path.join(HERE, "mae_extractor.npz"), **out)
+    print("mae_extractor: features", out["vt/features"][0, :3], out["vision_only/features"][0, :3])
+
+
 def run_vt_load(ref):
     import utils.pretrain_utils as pu  # the reference's own file (cv2 / SB3 logger stubbed)
     g = np.random.default_rng(7)
@@ -319,9 +358,13 @@ def main():
     if "--ppo-only" in sys.argv:
         run_ppo_like(ref)
         return
+    if "--extractor-only" in sys.argv:
+        run_extractor(ref)
+        return
     if "--reconstruct-only" not in sys.argv:
         _main_cases(ref)
         run_ppo_like(ref)
+        run_extractor(ref)
     # F: reconstruct(): count rule int(r*n) (0.7*16 -> 11 image, 11 per sensor), both masking modes, default + vision-only
     run_reconstruct(ref, "recon_small", early_conv=False, ratio=0.75, mask_ratio=0.7, seed=31)
     run_reconstruct(ref, "recon_default_ratio", early_conv=False, ratio=0.8, mask_ratio=None, seed=32, use_tactile=False)

@@ -218,3 +218,21 @@ def test_ppo_like_update_with_adam(golden_dir):
         assert abs(float(loss) - float(z["losses"][i])) <= 2e-5 * float(z["losses"][i])
         for k in [f[len(f"step{i}/"):] for f in z.files if f.startswith(f"step{i}/")]:
             np.testing.assert_allclose(P[k].detach().numpy(), z[f"step{i}/{k}"], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["vt", "vision_only"])
+def test_mae_extractor(golden_dir, tag):
+    """The reference's MAEExtractor.forward (models/pretrain_models.py:788-841): vt_load -> get_embeddings -> 1-layer Transformer ->
+    mean over tokens, with and without tactile control, composed from the oracle pieces."""
+    z = _load(golden_dir, "mae_extractor")
+    fs = int(z["frame_stack"])
+    cfg = O.cfg_from_meta(z["meta"], 0.75)
+    P = {k[len("param/mae."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/mae.")}
+    PL = {k[len(tag + "/param/vit_layer."):]: torch.tensor(z[k]) for k in z.files if k.startswith(tag + "/param/vit_layer.")}
+    img = z[tag + "/obs/image"].transpose(0, 2, 3, 1, 4).reshape(3, 32, 32, -1)
+    tac = z[tag + "/obs/tactile"].reshape(3, -1, 16, 16)
+    x = O.vt_load({"image": img, "tactile": tac}, frame_stack=fs)
+    with torch.no_grad():
+        tok = O.get_embeddings(P, cfg, x, use_tactile=(tag == "vt"))
+        feat = O.transformer(tok, PL, "transformer.", 1, 4, 64).mean(1)
+    np.testing.assert_allclose(feat.numpy(), z[tag + "/features"], rtol=1e-4, atol=1e-5)

@@ -755,3 +755,30 @@ def test_ppo_like_update_golden(golden_dir, optimizer):
         named = dict(mae.named_parameters())
         for k in [f[len(f"step{i}/"):] for f in z.files if f.startswith(f"step{i}/")]:
             np.testing.assert_allclose(named[k].detach().cpu().numpy(), z[f"step{i}/{k}"], rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["vt", "vision_only"])
+def test_mae_extractor_golden(golden_dir, tag):
+    """m3l_amd.MAEExtractor against the reference's own MAEExtractor.forward (models/pretrain_models.py:788-841): features and the
+    gradients that reach the MAE encoder and the extra transformer layer, with and without tactile control."""
+    from m3l_amd import MAEExtractor
+    z = np.load(os.path.join(golden_dir, "mae_extractor.npz"))
+    fs = int(z["frame_stack"])
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=fs)
+    mae.load_state_dict({k[len("param/mae."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/mae.")}, strict=True)
+    ext = MAEExtractor(mae, 64, vision_only_control=(tag == "vision_only"), frame_stack=fs)
+    sd = {k[len(tag + "/param/vit_layer."):]: torch.tensor(z[k]) for k in z.files if k.startswith(tag + "/param/vit_layer.")}
+    missing, unexpected = ext.vit_layer.load_state_dict(sd, strict=False)
+    assert not unexpected and all(not m.startswith("transformer.") for m in missing)
+    ext = ext.to(DEV)
+    obs = {"image": torch.tensor(z[tag + "/obs/image"]).to(DEV), "tactile": torch.tensor(z[tag + "/obs/tactile"]).to(DEV)}
+    feat = ext(obs)
+    assert feat.shape == (3, 64) and ext.features_dim == 64
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), z[tag + "/features"], rtol=1e-3, atol=1e-4)
+    feat.square().mean().backward()
+    for name, p in (("mae.encoder.transformer.layers.0.0.to_qkv.weight", mae.encoder.transformer.layers[0][0].to_qkv.weight),
+                    ("vit_layer.transformer.layers.0.1.net.1.weight", ext.vit_layer.transformer.layers[0][1].net[1].weight)):
+        ref = z[f"{tag}/grad/{name}"]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-7, name

@@ -295,6 +295,49 @@ def run_extractor(ref):
     print("mae_extractor: features", out["vt/features"][0, :3], out["vision_only/features"][0, :3])
 
 
+def run_dino_cat_extractor():
+    """`MAEExtractor.forward` of the cfg-5 fusion head (models/pretrain_models_dino_cat_mae.py:793-904): get_embeddings -> 1-layer
+    Transformer -> mean, concatenated with `dino_model(middle RGB frame)`, through the 3-Linear MLP (eval mode: Dropout off).  The
+    frozen DINOv2 is replaced by a small deterministic stand-in (mean-pool + Linear): this fixture pins the GLUE — the frame-stack
+    reshape, the middle-frame slice `image[:, 3*mid-3 : 3*mid]`, the concat order and the MLP — not the image encoder
+    (tests/golden/dinov2_small.npz does that).  frame_stack = 4 (the script default), so the slice is channels 3..5."""
+    spec = importlib.util.spec_from_file_location("ref_dino_cat", os.path.join(REF, "models", "pretrain_models_dino_cat_mae.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    torch.manual_seed(81)
+    fs, B, D = 4, 2, 64
+    enc = m.VTT(image_size=28, tactile_size=28, image_patch_size=7, tactile_patch_size=7, dim=D, depth=1, heads=2, mlp_dim=128,
+                image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = m.VTMAE(encoder=enc, decoder_dim=D, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2,
+                  early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=fs)
+
+    class StandInDino(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(3, D)
+
+        def forward(self, x):
+            assert x.shape[1] == 3, x.shape
+            return self.proj(x.mean(dim=(2, 3)))
+
+    dino = StandInDino()
+    ext = m.MAEExtractor(None, dino, mae, D, False, fs).eval()
+    g = torch.Generator().manual_seed(82)
+    obs = {"image": torch.rand(B, fs, 28, 28, 3, generator=g), "tactile": torch.rand(B, fs, 6, 28, 28, generator=g) * 2 - 1}
+    out = {"obs/image": obs["image"].numpy().copy(), "obs/tactile": obs["tactile"].numpy().copy()}
+    with torch.no_grad():
+        feat = ext({k: v.clone() for k, v in obs.items()})
+    out["features"] = feat.numpy()
+    out.update({"param/mae." + k: v.detach().clone().numpy() for k, v in mae.state_dict().items()})
+    out.update({"param/ext." + k: v.detach().clone().numpy() for k, v in ext.state_dict().items()
+                if k.startswith(("vit_layer.transformer.", "mlp.", "query", "key_projection"))})
+    out["param/dino.proj.weight"], out["param/dino.proj.bias"] = dino.proj.weight.detach().numpy(), dino.proj.bias.detach().numpy()
+    out["meta"] = np.array([28, 28, 7, 7, D, 1, 2, 128, 3 * fs, 2, D, 1, 2, B], dtype=np.int64)
+    out["frame_stack"] = np.array(fs)
+    np.savez_compressed(os.path.join(HERE, "dino_cat_extractor.npz"), **out)
+    print("dino_cat_extractor: features", feat[0, :4].tolist())
+
+
 def run_vt_load(ref):
     import utils.pretrain_utils as pu  # the reference's own file (cv2 / SB3 logger stubbed)
     g = np.random.default_rng(7)
@@ -360,11 +403,13 @@ def main():
         return
     if "--extractor-only" in sys.argv:
         run_extractor(ref)
+        run_dino_cat_extractor()
         return
     if "--reconstruct-only" not in sys.argv:
         _main_cases(ref)
         run_ppo_like(ref)
         run_extractor(ref)
+        run_dino_cat_extractor()
     # F: reconstruct(): count rule int(r*n) (0.7*16 -> 11 image, 11 per sensor), both masking modes, default + vision-only
     run_reconstruct(ref, "recon_small", early_conv=False, ratio=0.75, mask_ratio=0.7, seed=31)
     run_reconstruct(ref, "recon_default_ratio", early_conv=False, ratio=0.8, mask_ratio=None, seed=32, use_tactile=False)

@@ -782,3 +782,38 @@ def test_mae_extractor_golden(golden_dir, tag):
                     ("vit_layer.transformer.layers.0.1.net.1.weight", ext.vit_layer.transformer.layers[0][1].net[1].weight)):
         ref = z[f"{tag}/grad/{name}"]
         assert np.abs(p.grad.cpu().numpy() - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-7, name
+
+
+def test_dino_cat_extractor_glue_golden(golden_dir):
+    """m3l_amd.DinoCatMAEExtractor against the reference's own class (models/pretrain_models_dino_cat_mae.py:793-904, eval mode) with a
+    stand-in `dino_model`: the frame-stack reshape, the middle-frame slice (frame_stack 4 -> channels 3..5), the concat order and the
+    3-Linear MLP are the reference's; the image encoder itself is pinned by the DINOv2 tests."""
+    from m3l_amd import DinoCatMAEExtractor
+    z = np.load(os.path.join(golden_dir, "dino_cat_extractor.npz"))
+    fs, D = int(z["frame_stack"]), 64
+
+    class StandInDino(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(3, D)
+
+        def forward(self, x):
+            assert x.shape[1] == 3
+            return self.proj(x.mean(dim=(2, 3)))
+
+    enc = VTT(image_size=28, tactile_size=28, image_patch_size=7, tactile_patch_size=7, dim=D, depth=1, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=D, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=fs)
+    mae.load_state_dict({k[len("param/mae."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/mae.")}, strict=True)
+    dino = StandInDino()
+    dino.load_state_dict({"proj.weight": torch.tensor(z["param/dino.proj.weight"]), "proj.bias": torch.tensor(z["param/dino.proj.bias"])})
+    ext = DinoCatMAEExtractor(dino, mae, D, vision_only_control=False, frame_stack=fs)
+    sd = {k[len("param/ext."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/ext.")}
+    missing, unexpected = ext.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith(("mae_model.", "dino_model.", "vit_layer.")) and not m.startswith("vit_layer.transformer.")
+                                  for m in missing), (missing, unexpected)
+    ext = ext.to(DEV).eval()
+    obs = {"image": torch.tensor(z["obs/image"]).to(DEV), "tactile": torch.tensor(z["obs/tactile"]).to(DEV)}
+    with torch.no_grad():
+        feat = ext(obs)
+    np.testing.assert_allclose(feat.cpu().numpy(), z["features"], rtol=1e-3, atol=1e-4)

@@ -32,6 +32,16 @@ CFG2 = dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_si
             dec_dim=192, dec_depth=4, dec_heads=3, ratio=0.75, num_tactiles=2)
 
 
+# BASELINE configs[3] (224x224 + 4x64x64, ViT-Small encoder, 4-layer decoder; sizes fixed by SURVEY.md section 8): selectable with
+# --workload cfg4 for the multi-GPU ViT-Small measurement; the headline line (no flag) is always configs[1]
+CFG4 = dict(image_size=224, tactile_size=64, image_patch_size=16, tactile_patch_size=8, dim=384, depth=12, heads=6, mlp_dim=1536,
+            dec_dim=192, dec_depth=4, dec_heads=3, ratio=0.75, num_tactiles=4)
+WORKLOADS = {
+    "cfg2": (CFG2, 256, "BASELINE configs[1]: VTT vision+tactile MAE, 64x64 RGB + 2x32x32 tactile, ViT-Tiny 192/12/3/768 + decoder 192/4/3/768, mask 0.75"),
+    "cfg4": (CFG4, 64, "BASELINE configs[3]: 224x224 RGB + 4x64x64 tactile, ViT-Small 384/12/6/1536 + decoder 192/4/3/768, mask 0.75"),
+}
+
+
 def fwd_flops_per_sample(c):
     """SURVEY.md section 8(d) formula (forward; fwd+bwd = 3x)."""
     def tf(n, D, depth, h, mlp):
@@ -110,7 +120,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="samples per GPU (weak scaling)")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the headline metric (default); cfg4 = ViT-Small")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's default (256 for cfg2)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="gemm_nt_glds64", help="kernel class event-timed inside the timed region ('' = every tracked class, diagnostic)")
@@ -149,7 +160,9 @@ def main():
     from m3l_amd import _lib
     from m3l_amd.parallel import FlatAdam, GradSync
     _lib.lib()
-    c = CFG2
+    c, default_batch, workload_name = WORKLOADS[args.workload]
+    if args.batch <= 0:
+        args.batch = default_batch
     mae = build_model(c, args.dtype, dev)
     sync = GradSync(mae, force_comm=force_comm)
     opt = FlatAdam(sync, lr=1e-4)                 # torch.optim.Adam semantics, one HIP launch over the flat buffers
@@ -211,8 +224,7 @@ def main():
     out = {"metric": "MAE fwd+bwd samples/sec (image+tactile)", "value": round(value, 1), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "BASELINE configs[1]: VTT vision+tactile MAE, 64x64 RGB + 2x32x32 tactile, ViT-Tiny "
-                                  "192/12/3/768 + decoder 192/4/3/768, mask 0.75",
+           "config": {"workload": workload_name,
                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                       "step": "zero_grad + mask + fwd + bwd + grad all-reduce + Adam" if not args.no_optimizer else "fwd + bwd (diagnostic)"},
            "loss": round(float(loss.detach()), 5)}
@@ -256,7 +268,7 @@ def main():
         # SURVEY 8d) at this sample rate over the dense bf16 MFMA peak of the GPUs used
         attn = 3 * attn_gemm_fwd_flops_per_sample(c) * value
         out["attention_gemm"] = {"tflops": round(attn / 1e12, 2), "frac_of_bf16_peak": round(attn / (world * PEAK_BF16_TFLOPS * 1e12), 5)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline(c)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

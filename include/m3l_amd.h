@@ -50,6 +50,10 @@ int m3l_version(void);
 int m3l_last_error(char* buf, size_t n);
 /* experimental: run the LayerNorms inside the epilogue of the neighbouring GEMM (returns the previous setting; default off) */
 int m3l_set_rowln(int enable);
+/* fused attention block (LN1 + QKV + attention + out-proj + residual + LN2 in one launch) for short sequences: bf16, dim 128 / 192,
+ * heads = dim / 64, n <= 64 — on by default (env M3L_ATTN_BLOCK=0 disables); returns the previous setting.  Writes the same
+ * activations as the unfused kernels. */
+int m3l_set_attn_block(int enable);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.

@@ -1,0 +1,355 @@
+// One launch for the attention half of a pre-norm transformer layer on a SHORT sequence (the MAE encoder: n = 48 visible tokens):
+//
+//     xn1 = LN1(x);  qkv = xn1 Wqkv^T;  o = softmax(q k^T / 8) v  per head;  x1 = x + o Wo^T + bo;  xn2 = LN2(x1)
+//
+// (vit_pytorch Attention.forward + the residual + the FeedForward's LayerNorm, models/pretrain_models.py:266).  The unfused path is
+// five dependent launches of 6-10 us each for 2-3 us worth of traffic; at M = B * 48 rows every one of them is launch / latency
+// bound.  Here one workgroup owns one sample: the sample's tokens never leave the CU between the five stages, the weights
+// (Wqkv, Wo: L2-resident) stream through a 2-stage LDS ring filled by a DMA-only wave, and every tensor the backward needs
+// (xn1, qkv, o, lse, x1, xn2) is written exactly as the unfused kernels write it, so the backward is unchanged.
+//
+// Workgroup = 13 waves: 12 compute waves (3 per SIMD: with one workgroup per CU, that is all the latency hiding there is), wave 12
+// only issues LDS-DMA (a wave that also reads LDS or stores gets its vmcnt waits
+// drained by the compiler / by its own stores — see DESIGN.md 4b).  bf16 operands, fp32 accumulation and statistics.
+// Supported: D = 64 KT (KT = 2, 3: LDS), heads = D / 64 (so to_out is a real projection with K = D), n <= 48 (3 row tiles).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int AB_CW = 12;                 // compute waves: (column tile 0..3) x (row tile 0..2) in the projections, (head, query tile) in attention
+constexpr int AB_THREADS = 64 * (AB_CW + 1);   // + the DMA wave
+constexpr float AB_SCALE = 0.125f;        // dim_head ** -0.5, dim_head = 64
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), every lane of the row gets the total: four VALU-rate DPP steps, no
+// LDS crossbar.  The LayerNorms give each ROW to one 16-lane group (a wave works on 4 rows at a time) so their two reductions per
+// row cost 8 DPP adds instead of 12 dependent ds_bpermute shuffles — with one wave per SIMD nothing else hides that latency.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+
+template <int KT> struct AbLayout {
+    static constexpr int D = 64 * KT;
+    static constexpr int XN_PITCH = D * 2 + 16;          // bytes; (pitch / 16) odd -> conflict-free ds_read_b128 over 16 rows
+    static constexpr int QKV_PITCH = 3 * D * 2 + 16;
+    static constexpr int Y_PITCH = D * 4 + 16;
+    static constexpr int ROWS = 64;
+    static constexpr int XN_BYTES = ROWS * XN_PITCH;      // xn1, later o
+    static constexpr int QKV_BYTES = ROWS * QKV_PITCH;    // q | k | v, later y (f32, needs ROWS * Y_PITCH <= QKV_BYTES)
+    static constexpr int WBLK = KT * 64 * 128;            // one 64-row weight block: KT sub-tiles [64 rows][128 B], chunk ^ (row & 7)
+    static constexpr int TOTAL = XN_BYTES + QKV_BYTES + 2 * WBLK;
+    static_assert(ROWS * Y_PITCH <= QKV_BYTES, "y must fit where qkv was");
+};
+
+template <int KT>
+__global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
+    const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
+    float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
+    float* __restrict__ x1_out, bf16* __restrict__ xn2_out) {
+    using Ly = AbLayout<KT>;
+    constexpr int D = Ly::D, H = KT, KSTEPS = 2 * KT;
+    constexpr int NB_QKV = 3 * KT, NB = 4 * KT;          // 64-row weight blocks: Wqkv then Wo
+    constexpr int NDMA = 8 * KT;                          // LDS-DMA instructions per block (1 KiB each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XN = smem;                                      // [64][XN_PITCH]  bf16 xn1, later o
+    char* QKV = smem + Ly::XN_BYTES;                      // [64][QKV_PITCH] bf16 q|k|v, later y f32 [64][Y_PITCH]
+    char* WR = QKV + Ly::QKV_BYTES;                       // 2 x WBLK
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* gl_vp;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x;
+    const long row0 = (long)b * n;
+    const int RT = (n + 15) >> 4;                         // 16-row tiles that hold real rows
+
+    if (wave == AB_CW) {
+        // ------------------------------------------------------------------ DMA wave
+        const int srow = lane >> 3, spc = lane & 7;
+        auto issue = [&](int blk) {
+            const bf16* Wsrc = blk < NB_QKV ? Wqkv + (long)blk * 64 * D : Wo + (long)(blk - NB_QKV) * 64 * D;
+            char* dst = WR + (blk & 1) * Ly::WBLK;
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) {
+                const bf16* src = Wsrc + (long)(8 * rg + srow) * D + ((spc ^ srow) << 3);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    __builtin_amdgcn_global_load_lds((gl_vp)(src + kt * 64), (lds_vp)(dst + kt * 8192 + rg * 1024), 16, 0, 0);
+            }
+        };
+        issue(0);
+        issue(1);
+        __builtin_amdgcn_s_barrier();                                     // B0 (xn1 ready; nothing to do here)
+        for (int blk = 0; blk < NB; ++blk) {
+            if (blk == NB_QKV) __builtin_amdgcn_s_barrier();              // B2 (o ready)
+            if (blk + 1 < NB) {                                           // loads retire in order: only block blk+1 may remain
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (NDMA == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                 // R_blk: block landed
+            __builtin_amdgcn_s_barrier();                                 // C_blk: block consumed
+            if (blk + 2 < NB) issue(blk + 2);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    // ---- LN1: wave w owns rows 4 w .. 4 w + 3 (row = 4 w + g): the row's 16 lanes hold KT float4 chunks (columns 4 (li + 16 c))
+    {
+        const int r = 4 * wave + g;
+        f32x4 xr[KT];
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+            xr[c] = (r < n) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) s1 += (xr[c][0] + xr[c][1]) + (xr[c][2] + xr[c][3]);
+        const float mean = row16_sum(s1) / D;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const f32x4 d = xr[c] - mean;
+            xr[c] = d;
+            s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = rsqrtf(row16_sum(s2) / D + eps);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const f32x4 y = xr[c] * rstd * *reinterpret_cast<const f32x4*>(ln1_w + 4 * (li + 16 * c)) + *reinterpret_cast<const f32x4*>(ln1_b + 4 * (li + 16 * c));
+            bf16x4 pk;
+            pk[0] = (bf16)y[0]; pk[1] = (bf16)y[1]; pk[2] = (bf16)y[2]; pk[3] = (bf16)y[3];
+            if (r >= n) pk[0] = pk[1] = pk[2] = pk[3] = (bf16)0.f;       // padding rows: zeros (their products are never stored)
+            *reinterpret_cast<bf16x4*>(XN + r * Ly::XN_PITCH + 8 * (li + 16 * c)) = pk;
+            if (r < n) *reinterpret_cast<bf16x4*>(xn1_out + (row0 + r) * D + 4 * (li + 16 * c)) = pk;
+        }
+    }
+    // key / value rows past the last computed row tile are read (masked) by the 32-key attention tiles: make them finite
+    for (int id = tid; id < (64 - 16 * RT) * (Ly::QKV_PITCH / 16); id += 64 * AB_CW) {
+        const int r = 16 * RT + id / (Ly::QKV_PITCH / 16), c = id % (Ly::QKV_PITCH / 16);
+        *reinterpret_cast<uint4*>(QKV + r * Ly::QKV_PITCH + c * 16) = uint4{0u, 0u, 0u, 0u};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B0: xn1 in LDS
+
+    // ---- a 64-column block of A[48 x D] (LDS, row pitch PITCH) times W block^T: wave (ct, rt) owns one 16 x 16 tile
+    const int ct = wave & 3, rt = wave >> 2;
+    auto block_mma = [&](const char* Abase, int pitch, const char* Wb) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int wrow = 16 * ct + li;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<bf16> fw, fa;
+            fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+            fa.v = *reinterpret_cast<const bf16x8*>(Abase + (16 * rt + li) * pitch + (ks * 32 + 8 * g) * 2);
+            acc = mma16(fa, fw, acc);
+        }
+        return acc;
+    };
+
+    // ---- QKV projection: 3 KT blocks; results (C layout: row 4g + r, col li) -> QKV LDS as bf16
+    for (int blk = 0; blk < NB_QKV; ++blk) {
+        __builtin_amdgcn_s_barrier();                                     // R_blk
+        if (rt < RT) {
+            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk & 1) * Ly::WBLK);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<bf16*>(QKV + (16 * rt + 4 * g + r) * Ly::QKV_PITCH + (64 * blk + 16 * ct + li) * 2) = (bf16)acc[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // C_blk
+    }
+
+    // ---- qkv -> global (what the unfused to_qkv GEMM writes): 16-byte row segments, all compute threads
+    {
+        constexpr int CPR = 3 * D / 8;                                    // 16-byte chunks per row
+        for (int id = tid; id < n * CPR; id += 64 * AB_CW) {
+            const int r = id / CPR, c = id % CPR;
+            *reinterpret_cast<uint4*>(qkv_out + (row0 + r) * 3 * D + c * 8) = *reinterpret_cast<const uint4*>(QKV + r * Ly::QKV_PITCH + c * 16);
+        }
+    }
+
+    // ---- attention: wave w = head w (H <= 4).  S^T = K Q^T per 16-query tile, online softmax over 32-key tiles, O^T = V^T P^T.
+    if (wave < H * RT) {
+        const int hh = wave / RT;
+        const char* Qb = QKV + hh * 128;                                  // column offset of q_h (64 bf16 = 128 B)
+        const char* Kb = QKV + (D + hh * 64) * 2;
+        const bf16* Vb = reinterpret_cast<const bf16*>(QKV + (2 * D + hh * 64) * 2);
+        constexpr int VLD = Ly::QKV_PITCH / 2;                            // row pitch of the LDS tile in elements
+        const int ntile = (n + 31) >> 5;
+        {
+            const int qt = wave % RT;
+            const int q = 16 * qt + li;
+            Frag<bf16> fq[2];
+            fq[0].v = *reinterpret_cast<const bf16x8*>(Qb + q * Ly::QKV_PITCH + (8 * g) * 2);
+            fq[1].v = *reinterpret_cast<const bf16x8*>(Qb + q * Ly::QKV_PITCH + (32 + 8 * g) * 2);
+            f32x4 oacc[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float m = -INFINITY, lsum = 0.f;
+            for (int kt = 0; kt < ntile; ++kt) {
+                f32x4 s[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        Frag<bf16> fk;
+                        fk.v = *reinterpret_cast<const bf16x8*>(Kb + (32 * kt + 16 * t + li) * Ly::QKV_PITCH + (ks * 32 + 8 * g) * 2);
+                        s[t] = mma16(fk, fq[ks], s[t]);
+                    }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 32 + 16 * t + 4 * g + r;
+                        const float v = (key < n) ? s[t][r] * AB_SCALE : -INFINITY;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m, mx);
+                const float alpha = __expf(m - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __expf(s[t][r] - mn);
+                        s[t][r] = p;
+                        ps += p;
+                    }
+                lsum = lsum * alpha + ps;
+                m = mn;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) oacc[d] *= alpha;
+                const Frag<bf16> fp = acc_to_frag<bf16>(s[0], s[1]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const Frag<bf16> fv = load_ks<KMAP_ACC>(Vb, VLD, 32 * kt, 16 * d, lane);
+                    oacc[d] = mma16(fv, fp, oacc[d]);
+                }
+            }
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            const float inv = 1.0f / lsum;
+            // o (transposed accumulator: row = query li, columns 16 d + 4 g + r) -> LDS (XN region) and global
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 pk;
+                pk[0] = (bf16)(oacc[d][0] * inv); pk[1] = (bf16)(oacc[d][1] * inv);
+                pk[2] = (bf16)(oacc[d][2] * inv); pk[3] = (bf16)(oacc[d][3] * inv);
+                if (q >= n) pk[0] = pk[1] = pk[2] = pk[3] = (bf16)0.f;
+                *reinterpret_cast<bf16x4*>(XN + q * Ly::XN_PITCH + (hh * 64 + 16 * d + 4 * g) * 2) = pk;
+                if (q < n) *reinterpret_cast<bf16x4*>(o_out + (row0 + q) * D + hh * 64 + 16 * d + 4 * g) = pk;
+            }
+            if (q < n && g == 0) lse_out[((long)b * H + hh) * n + q] = m + __logf(lsum);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B2: o in LDS, qkv no longer needed
+
+    // ---- out-projection: KT blocks of Wo; y (f32) -> LDS where qkv was
+    float* Y = reinterpret_cast<float*>(QKV);
+    constexpr int YLD = Ly::Y_PITCH / 4;
+    for (int blk = NB_QKV; blk < NB; ++blk) {
+        __builtin_amdgcn_s_barrier();                                     // R_blk
+        if (rt < RT) {
+            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk & 1) * Ly::WBLK);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * rt + 4 * g + r) * YLD + 64 * (blk - NB_QKV) + 16 * ct + li] = acc[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // C_blk
+    }
+
+    // ---- x1 = x + y + bo (fp32 residual stream), xn2 = LN2(x1): same row -> 16-lane mapping as LN1
+    {
+        const int r = 4 * wave + g;
+        const bool ok = r < n;
+        f32x4 v[KT];
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v[c] = *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) + *reinterpret_cast<const f32x4*>(bo + 4 * (li + 16 * c)) +
+                       *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c));
+                *reinterpret_cast<f32x4*>(x1_out + (row0 + r) * D + 4 * (li + 16 * c)) = v[c];
+            }
+            s1 += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        const float mean = row16_sum(s1) / D;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const f32x4 d = v[c] - mean;
+            v[c] = d;
+            s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = rsqrtf(row16_sum(s2) / D + eps);
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < KT; ++c) {
+                const f32x4 y = v[c] * rstd * *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c)) + *reinterpret_cast<const f32x4*>(ln2_b + 4 * (li + 16 * c));
+                bf16x4 pk;
+                pk[0] = (bf16)y[0]; pk[1] = (bf16)y[1]; pk[2] = (bf16)y[2]; pk[3] = (bf16)y[3];
+                *reinterpret_cast<bf16x4*>(xn2_out + (row0 + r) * D + 4 * (li + 16 * c)) = pk;
+            }
+        }
+    }
+}
+
+int g_ab_state = 0;   // 0 = unknown, 1 = on, -1 = off
+
+}  // namespace
+
+extern "C" int m3l_set_attn_block(int enable) {
+    const int old = g_ab_state == -1 ? 0 : 1;
+    g_ab_state = enable ? 1 : -1;
+    return old;
+}
+
+// 1 when the fused attention-block kernel takes this problem
+int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out) {
+    if (!g_ab_state) {
+        const char* e = getenv("M3L_ATTN_BLOCK");
+        g_ab_state = (e && e[0] == '0') ? -1 : 1;
+    }
+    if (g_ab_state != 1) return 0;
+    return dtype == 1 && project_out && (D == 128 || D == 192) && heads * 64 == D && n >= 1 && n <= 48;
+}
+
+int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
+                       const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,
+                       float* x1, void* xn2, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<3>::TOTAL));
+        inited = 1;
+    }
+    ProfScope prof("attn_block_fwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64, st);
+#define AB_LAUNCH(KT)                                                                                                              \
+    attn_block_fwd_kernel<KT><<<B, AB_THREADS, AbLayout<KT>::TOTAL, st>>>(x, ln1_w, ln1_b, (const bf16*)wqkv, (const bf16*)wo, bo, ln2_w, \
+                                                                         ln2_b, eps, n, (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse, x1, (bf16*)xn2)
+    M3L_CHECK(D == 128 || D == 192, "attn_block: D=%d unsupported", D);
+    if (D == 128) AB_LAUNCH(2);
+    else AB_LAUNCH(3);
+#undef AB_LAUNCH
+    M3L_LAUNCH_CHECK();
+    return 0;
+}

@@ -117,6 +117,11 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
 int m3l_gemm_init();
 int m3l_gemm_nt_colsum_rows(int M, int N);   // number of partial rows written through GemmEpi::colsum_part
 
+// fused LN1 + QKV + attention + out-proj + residual + LN2 for short sequences (attn_block.hip)
+int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out);
+int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
+                       const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,
+                       float* x1, void* xn2, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

@@ -459,11 +459,19 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
                     *ln2_b = (const float*)t[6], *fc1_b = (const float*)t[8], *fc2_b = (const float*)t[10];
         if (l == 1 && prep_done) M3L_HIP(hipStreamWaitEvent(st, prep_done, 0));
 
-        if (!fuse || l == 0) {
+        const bool block = !fuse && m3l_attn_block_supported(dt, D, c->heads, n, c->project_out);
+        if (block) {
+            // the whole attention half of the layer in one launch (short sequences: the MAE encoder)
+            if (m3l_attn_block_fwd(D, B, n, x, ln1_w, ln1_b, L.wqkv, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.xn1, L.qkv, L.o, L.lse, L.x1,
+                                   L.xn2, st))
+                return 1;
+        }
+        if (!block && (!fuse || l == 0)) {
             if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
         }
         GemmEpi e = epi0(3 * HD);
         e.out_t = L.qkv;
+        if (!block) {
         if (m3l_gemm_nt(dt, L.xn1, D, L.wqkv, D, M, 3 * HD, D, &e, st)) return 1;
         if (m3l_attn_fwd(dt, L.qkv, L.o, L.lse, B, n, c->heads, st)) return 1;
         if (c->project_out && fuse) {
@@ -480,6 +488,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
                 if (m3l_axpy_t(dt, x, L.o, (long)M * D, L.x1, st)) return 1;
             }
             if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
+        }
         }
         e = epi0(mlp);
         e.bias = fc1_b; e.act = 1; e.out_pre = L.u; e.out_t = L.h;

@@ -817,3 +817,46 @@ def test_dino_cat_extractor_glue_golden(golden_dir):
     with torch.no_grad():
         feat = ext(obs)
     np.testing.assert_allclose(feat.cpu().numpy(), z["features"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("D,heads,n_img_hw,B", [(192, 3, 64, 5), (128, 2, 32, 3)])
+def test_fused_attention_block_matches_unfused(D, heads, n_img_hw, B):
+    """Short-sequence encoder layers run LN1 + QKV + attention + out-proj + residual + LN2 as ONE launch (attn_block.hip).  The whole
+    MAE step with it against the same step on the five separate kernels: loss and every gradient (the backward reads the
+    activations the fused kernel saved)."""
+    from m3l_amd import _lib as L
+    torch.manual_seed(0)
+    enc = VTT(image_size=n_img_hw, tactile_size=n_img_hw // 2, image_patch_size=8, tactile_patch_size=4, dim=D, depth=3, heads=heads,
+              mlp_dim=2 * D, num_tactiles=2)
+    mae = VTMAE(encoder=enc, decoder_dim=D, masking_ratio=0.75, decoder_depth=1, decoder_heads=heads, num_tactiles=2,
+                compute_dtype="bf16").to(DEV)
+    with torch.no_grad():
+        for p in mae.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n = (n_img_hw // 8) ** 2
+    x = {"image": torch.rand(B, 3, n_img_hw, n_img_hw, device=DEV, generator=g),
+         "tactile1": torch.rand(B, 3, n_img_hw // 2, n_img_hw // 2, device=DEV, generator=g),
+         "tactile2": torch.rand(B, 3, n_img_hw // 2, n_img_hw // 2, device=DEV, generator=g)}
+    noises = [torch.rand(B, n, device=DEV, generator=g) for _ in range(3)]
+    res = []
+    old = L.lib().m3l_set_attn_block(1)
+    try:
+        for on in (1, 0):
+            L.lib().m3l_set_attn_block(on)
+            mae.zero_grad(set_to_none=True)
+            loss = mae(x, mask_noise=noises)
+            loss.backward()
+            emb = mae.get_embeddings(x, eval=False).detach().clone()          # all tokens: decoder-length sequences stay unfused
+            res.append((float(loss.detach()), emb, {k: p.grad.clone() for k, p in mae.named_parameters() if p.grad is not None}))
+    finally:
+        L.lib().m3l_set_attn_block(old)
+    assert abs(res[0][0] - res[1][0]) <= 2e-3 * abs(res[1][0]), (res[0][0], res[1][0])
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 3e-2 * res[1][1].abs().max().item()
+    num = den = 0.0
+    for k, g1 in res[0][2].items():
+        g0 = res[1][2][k]
+        num += float((g1 - g0).double().square().sum())
+        den += float(g0.double().square().sum())
+    assert (num / den) ** 0.5 <= 2e-2, (num / den) ** 0.5

@@ -40,12 +40,14 @@ template <int KT> struct AbLayout {
     static constexpr int XN_PITCH = D * 2 + 16;          // bytes; (pitch / 16) odd -> conflict-free ds_read_b128 over 16 rows
     static constexpr int QKV_PITCH = 3 * D * 2 + 16;
     static constexpr int Y_PITCH = D * 4 + 16;
-    static constexpr int ROWS = 64;
+    static constexpr int ROWS = 48;                       // n <= 48: three 16-row tiles
     static constexpr int XN_BYTES = ROWS * XN_PITCH;      // xn1, later o
     static constexpr int QKV_BYTES = ROWS * QKV_PITCH;    // q | k | v, later y (f32, needs ROWS * Y_PITCH <= QKV_BYTES)
     static constexpr int WBLK = KT * 64 * 128;            // one 64-row weight block: KT sub-tiles [64 rows][128 B], chunk ^ (row & 7)
-    static constexpr int TOTAL = XN_BYTES + QKV_BYTES + 2 * WBLK;
+    static constexpr int NSTAGE = 3;                      // weight ring: two blocks in flight while one is multiplied
+    static constexpr int TOTAL = XN_BYTES + QKV_BYTES + NSTAGE * WBLK;
     static_assert(ROWS * Y_PITCH <= QKV_BYTES, "y must fit where qkv was");
+    static_assert(KT == 2 || KT == 3, "vmcnt immediates in the DMA wave are 16 / 24");
 };
 
 template <int KT>
@@ -59,9 +61,9 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     constexpr int NB_QKV = 3 * KT, NB = 4 * KT;          // 64-row weight blocks: Wqkv then Wo
     constexpr int NDMA = 8 * KT;                          // LDS-DMA instructions per block (1 KiB each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* XN = smem;                                      // [64][XN_PITCH]  bf16 xn1, later o
-    char* QKV = smem + Ly::XN_BYTES;                      // [64][QKV_PITCH] bf16 q|k|v, later y f32 [64][Y_PITCH]
-    char* WR = QKV + Ly::QKV_BYTES;                       // 2 x WBLK
+    char* XN = smem;                                      // [48][XN_PITCH]  bf16 xn1, later o
+    char* QKV = smem + Ly::XN_BYTES;                      // [48][QKV_PITCH] bf16 q|k|v, later y f32 [48][Y_PITCH]
+    char* WR = QKV + Ly::QKV_BYTES;                       // NSTAGE x WBLK
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* gl_vp;
 
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         const int srow = lane >> 3, spc = lane & 7;
         auto issue = [&](int blk) {
             const bf16* Wsrc = blk < NB_QKV ? Wqkv + (long)blk * 64 * D : Wo + (long)(blk - NB_QKV) * 64 * D;
-            char* dst = WR + (blk & 1) * Ly::WBLK;
+            char* dst = WR + (blk % Ly::NSTAGE) * Ly::WBLK;
 #pragma unroll
             for (int rg = 0; rg < 8; ++rg) {
                 const bf16* src = Wsrc + (long)(8 * rg + srow) * D + ((spc ^ srow) << 3);
@@ -89,18 +91,20 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         issue(1);
         __builtin_amdgcn_s_barrier();                                     // B0 (xn1 ready; nothing to do here)
         for (int blk = 0; blk < NB; ++blk) {
-            if (blk == NB_QKV) __builtin_amdgcn_s_barrier();              // B2 (o ready)
+            if (blk == NB_QKV) {
+                __builtin_amdgcn_s_barrier();                             // B1 (qkv complete)
+                __builtin_amdgcn_s_barrier();                             // B2 (o ready)
+            }
             if (blk + 1 < NB) {                                           // loads retire in order: only block blk+1 may remain
                 if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (NDMA == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();                                 // R_blk: block landed
-            __builtin_amdgcn_s_barrier();                                 // C_blk: block consumed
-            if (blk + 2 < NB) issue(blk + 2);
+            __builtin_amdgcn_s_barrier();                                 // R_blk: block landed; every compute wave is done with block blk-1
+            if (blk + 2 < NB) issue(blk + 2);                             // into the stage block blk-1 occupied
         }
+        __builtin_amdgcn_s_barrier();                                     // B3 (y complete)
         return;
     }
 
@@ -134,11 +138,6 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
             if (r < n) *reinterpret_cast<bf16x4*>(xn1_out + (row0 + r) * D + 4 * (li + 16 * c)) = pk;
         }
     }
-    // key / value rows past the last computed row tile are read (masked) by the 32-key attention tiles: make them finite
-    for (int id = tid; id < (64 - 16 * RT) * (Ly::QKV_PITCH / 16); id += 64 * AB_CW) {
-        const int r = 16 * RT + id / (Ly::QKV_PITCH / 16), c = id % (Ly::QKV_PITCH / 16);
-        *reinterpret_cast<uint4*>(QKV + r * Ly::QKV_PITCH + c * 16) = uint4{0u, 0u, 0u, 0u};
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0: xn1 in LDS
 
@@ -161,14 +160,14 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     for (int blk = 0; blk < NB_QKV; ++blk) {
         __builtin_amdgcn_s_barrier();                                     // R_blk
         if (rt < RT) {
-            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk & 1) * Ly::WBLK);
+            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk % Ly::NSTAGE) * Ly::WBLK);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 *reinterpret_cast<bf16*>(QKV + (16 * rt + 4 * g + r) * Ly::QKV_PITCH + (64 * blk + 16 * ct + li) * 2) = (bf16)acc[r];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                     // C_blk
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B1: q | k | v complete in LDS
 
     // ---- qkv -> global (what the unfused to_qkv GEMM writes): 16-byte row segments, all compute threads
     {
@@ -199,14 +198,17 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
             float m = -INFINITY, lsum = 0.f;
             for (int kt = 0; kt < ntile; ++kt) {
                 f32x4 s[2];
+                const bool hi_ok = 32 * kt + 16 < 16 * RT;            // the second 16 keys of the tile exist in LDS (rows < 16 RT)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (t == 0 || hi_ok) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        Frag<bf16> fk;
-                        fk.v = *reinterpret_cast<const bf16x8*>(Kb + (32 * kt + 16 * t + li) * Ly::QKV_PITCH + (ks * 32 + 8 * g) * 2);
-                        s[t] = mma16(fk, fq[ks], s[t]);
+                        for (int ks = 0; ks < 2; ++ks) {
+                            Frag<bf16> fk;
+                            fk.v = *reinterpret_cast<const bf16x8*>(Kb + (32 * kt + 16 * t + li) * Ly::QKV_PITCH + (ks * 32 + 8 * g) * 2);
+                            s[t] = mma16(fk, fq[ks], s[t]);
+                        }
                     }
                 }
                 float mx = -INFINITY;
@@ -239,7 +241,17 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
                 const Frag<bf16> fp = acc_to_frag<bf16>(s[0], s[1]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const Frag<bf16> fv = load_ks<KMAP_ACC>(Vb, VLD, 32 * kt, 16 * d, lane);
+                    // V^T fragment (k = key, KMAP_ACC): keys 32 kt + 4 g .. +3 and, if present, + 16
+                    const int q4 = li >> 2, p4 = li & 3;
+                    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+                    const bf16* vp = Vb + (32 * kt + 4 * g + q4) * VLD + 16 * d + 4 * p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)vp);
+                    bf16x4 hi;
+                    hi[0] = hi[1] = hi[2] = hi[3] = (bf16)0.f;
+                    if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(vp + 16 * VLD));
+                    Frag<bf16> fv;
+                    fv.v[0] = lo[0]; fv.v[1] = lo[1]; fv.v[2] = lo[2]; fv.v[3] = lo[3];
+                    fv.v[4] = hi[0]; fv.v[5] = hi[1]; fv.v[6] = hi[2]; fv.v[7] = hi[3];
                     oacc[d] = mma16(fv, fp, oacc[d]);
                 }
             }
@@ -268,13 +280,13 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     for (int blk = NB_QKV; blk < NB; ++blk) {
         __builtin_amdgcn_s_barrier();                                     // R_blk
         if (rt < RT) {
-            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk & 1) * Ly::WBLK);
+            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk % Ly::NSTAGE) * Ly::WBLK);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Y[(16 * rt + 4 * g + r) * YLD + 64 * (blk - NB_QKV) + 16 * ct + li] = acc[r];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                     // C_blk
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B3: y complete in LDS
 
     // ---- x1 = x + y + bo (fp32 residual stream), xn2 = LN2(x1): same row -> 16-lane mapping as LN1
     {

@@ -122,6 +122,10 @@ int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out
 int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
                        const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,
                        float* x1, void* xn2, hipStream_t st);
+// fused fc1 + GELU + fc2 + residual for short sequences (mlp_block.hip), companion of the attention block
+int m3l_mlp_block_supported(int dtype, int D, int mlp, int n);
+int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2,
+                      const float* b2, void* u, void* h, float* xout, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

@@ -490,6 +490,12 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
         }
         }
+        if (block && m3l_mlp_block_supported(dt, D, mlp, n)) {
+            // the feed-forward half in one launch as well
+            if (m3l_mlp_block_fwd(D, mlp, B, n, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
+            x = L.xout;
+            continue;
+        }
         e = epi0(mlp);
         e.bias = fc1_b; e.act = 1; e.out_pre = L.u; e.out_t = L.h;
         if (m3l_gemm_nt(dt, L.xn2, D, L.w1, D, M, mlp, D, &e, st)) return 1;

@@ -4,7 +4,7 @@
 //
 // (vit_pytorch FeedForward.forward + the residual, models/pretrain_models.py:266; xn2 = LN2(x1) comes from the attention block).
 // Companion of attn_block.hip, same structure: one workgroup per sample, 12 compute waves + one DMA-only wave that streams the
-// weights through a 3-stage LDS ring — here alternating a 64-row block of W1 (64 hidden units x D) and the matching 64-column
+// weights through a 4-stage LDS ring — here alternating a 64-row block of W1 (64 hidden units x D) and the matching 64-column
 // block of W2 (D outputs x 64 hidden units), so the hidden activation is produced and consumed 64 units at a time and never
 // exists as a whole in LDS.  u and h (what the backward needs) leave through a small LDS staging tile as 128-byte row segments.
 // Supported: bf16, D = 128 / 192, mlp_dim % 64 == 0, n <= 48.
@@ -28,7 +28,7 @@ template <int KT> struct MbLayout {
     static constexpr int XN_BYTES = ROWS * XN_PITCH;
     static constexpr int HC_BYTES = ROWS * HC_PITCH;      // per chunk buffer; 2 (double buffer) x 2 (u, h)
     static constexpr int WBLK = KT * 64 * 128;
-    static constexpr int NSTAGE = 3;
+    static constexpr int NSTAGE = 4;                      // three blocks in flight while one is multiplied (the stream is L2-latency bound)
     static constexpr int TOTAL = XN_BYTES + 4 * HC_BYTES + NSTAGE * WBLK;
     static_assert(ROWS * Y_PITCH <= NSTAGE * WBLK, "the fp32 output staging tile reuses the weight ring");
     static_assert(KT == 2 || KT == 3, "vmcnt immediates in the DMA wave are 16 / 24");
@@ -84,16 +84,21 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
         };
         issue(0);
         issue(1);
+        if (NB > 2) issue(2);
         __builtin_amdgcn_s_barrier();                                     // B0 (xn2 in LDS)
         for (int blk = 0; blk < NB; ++blk) {
-            if (blk + 1 < NB) {
+            // loads retire in order: blocks blk+1 and blk+2 (NDMA instructions each) may remain in flight
+            if (blk + 2 < NB) {
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            } else if (blk + 1 < NB) {
                 if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();                                 // block landed; every compute wave is done with block blk-1
-            if (blk + 2 < NB) issue(blk + 2);
+            if (blk + 3 < NB) issue(blk + 3);                             // into the stage block blk-1 occupied
         }
         __builtin_amdgcn_s_barrier();                                     // BE1: every wave is done with the last W2 block (ring -> y)
         __builtin_amdgcn_s_barrier();                                     // BE2: y complete

@@ -126,6 +126,10 @@ int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, 
 int m3l_mlp_block_supported(int dtype, int D, int mlp, int n);
 int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* u, void* h, float* xout, hipStream_t st);
+int m3l_mlp_block_bwd_supported(int dtype, int D, int mlp, int n);
+// dgrad chain of the feed-forward half + LN2 backward; cs_part [B][mlp] and ln_part [B][3 D] are per-sample partial rows
+int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u,
+                      const void* w2T, const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

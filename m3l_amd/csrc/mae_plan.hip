@@ -215,8 +215,8 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     }
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
-    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)m3l_gemm_nt_colsum_rows((int)M, (int)mlp) * mlp);
-    w.ln_part_stride = (size_t)m3l_ln_bwd_blocks((int)M) * 3 * D;
+    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B) * mlp);   // B: one partial row per sample (block kernels)
+    w.ln_part_stride = (size_t)std::max(m3l_ln_bwd_blocks((int)M), B) * 3 * D;
     w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
     return w;
@@ -549,7 +549,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     batches[0].count = 0;
     batches[0].D = D;
     const int lnG = m3l_ln_bwd_blocks(M);
-    auto ln_slot = [&](int id, float* dgamma, float* dbeta, float* dbias) -> float* {
+    auto ln_slot = [&](int id, float* dgamma, float* dbeta, float* dbias, int G = 0) -> float* {
         if (batches.back().count == M3L_REDUCE_BATCH_MAX) {
             batches.emplace_back();
             batches.back().count = 0;
@@ -557,7 +557,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         ReduceBatch& rb = batches.back();
         float* slot = w.ln_part + (size_t)id * w.ln_part_stride;
-        rb.it[rb.count++] = ReduceBatchItem{slot, {dgamma, dbeta, dbias}, lnG};
+        rb.it[rb.count++] = ReduceBatchItem{slot, {dgamma, dbeta, dbias}, G > 0 ? G : lnG};
         return slot;
     };
     const float* x_last = c->depth ? w.L[c->depth - 1].xout : x_in;
@@ -587,10 +587,21 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         // (dx_t[cur] was already written by layer l+1's last kernel, which waited on the same event — see below)
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
         GemmEpi e = epi0(mlp);
+        const bool mlp_block = !fuse && m3l_mlp_block_bwd_supported(dt, D, mlp, n);
+        int cs_rows = csrows;
+        if (mlp_block) {
+            // short sequences: du, its column sums, dxn2 and the LN2 backward in one launch; one partial row per sample
+            cs_rows = B;
+            if (m3l_mlp_block_bwd(D, mlp, B, n, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
+                                  w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, B), st))
+                return 1;
+        } else {
         e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2[cur];
         if (m3l_gemm_nt(dt, w.dx_t[cur], D, L.w2T, D, M, mlp, D, &e, st)) return 1;                   // du = (dx W2) * gelu'(u)
         // (the per-row-block column sums in scratch2[cur] = fc1 bias gradient partials are reduced by the wgrad group's reduce)
-        if (fuse) {
+        }
+        if (mlp_block) {
+        } else if (fuse) {
             // dxn2 = du W1 and the LN2 backward in one kernel: dx1 = dx + dLN(dxn2) (in place) + compute-type copy + partials
             RowLnEpi r;
             memset(&r, 0, sizeof(r));
@@ -628,7 +639,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             pr[np++] = TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};             // dW1 = du^T xn2
             pr[np++] = TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}; // dWqkv = dqkv^T xn1
             if (c->project_out) pr[np++] = TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
-            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2, w.scratch2[cur], csrows, mlp, g[8])) return 1;
+            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2, w.scratch2[cur], cs_rows, mlp, g[8])) return 1;
             wg_done[cur] = side_event();
             M3L_HIP(hipEventRecord(wg_done[cur], s2));
         }

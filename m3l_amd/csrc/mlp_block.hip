@@ -19,6 +19,14 @@ namespace {
 constexpr int MB_CW = 12;
 constexpr int MB_THREADS = 64 * (MB_CW + 1);
 
+__device__ __forceinline__ float row16_sum_mb(float v) {   // sum over the 16 lanes of a DPP row (see attn_block.hip)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
 template <int KT> struct MbLayout {
     static constexpr int D = 64 * KT;
     static constexpr int XN_PITCH = D * 2 + 16;          // (pitch / 16) odd: conflict-free ds_read_b128 over 16 rows
@@ -202,10 +210,276 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the same half layer, dgrad chain only (the weight gradients stay with the grouped TN GEMM on the side stream, which
+// reads du and dx1_t written here):
+//     du   = (dx_t W2) * gelu'(u)                    [n, mlp]   (+ its column sums = fc1 bias gradient, one partial row per sample)
+//     dxn2 = du W1                                    [n, D]     (kept in fp32, never leaves the CU)
+//     dx1  = dx + LN2-backward(dxn2; x1, gamma2)      in place, + compute-type copy, + [3 D] partials (dgamma2 | dbeta2 | colsum dx1)
+// Same ring / barrier structure as the forward with (W2^T, W1^T) in place of (W1, W2): block 2c = rows 64c.. of W2^T [mlp][D],
+// block 2c + 1 = columns 64c.. of W1^T [D][mlp].  u arrives one chunk ahead through registers.
+template <int KT>
+__global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+                                                                     const float* __restrict__ x1, const float* __restrict__ ln2_w,
+                                                                     const bf16* __restrict__ u, const bf16* __restrict__ W2T,
+                                                                     const bf16* __restrict__ W1T, float eps, int n, int mlp,
+                                                                     bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
+                                                                     float* __restrict__ cs_part, float* __restrict__ ln_part) {
+    using Ly = MbLayout<KT>;
+    constexpr int D = Ly::D, KSTEPS = 2 * KT;
+    constexpr int NDMA = 8 * KT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XN = smem;                                      // [48][XN_PITCH] bf16 dx_t; later (with HC) the LayerNorm partials
+    char* HC = smem + Ly::XN_BYTES;                       // [2][u | du][48][HC_PITCH]
+    char* WR = HC + 4 * Ly::HC_BYTES;                     // NSTAGE x WBLK, later dxn2 f32 [48][Y_PITCH]
+    float* CS = reinterpret_cast<float*>(WR + Ly::NSTAGE * Ly::WBLK);     // [3][mlp] column sums of du per row tile
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* gl_vp;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x;
+    const long row0 = (long)b * n;
+    const int RT = (n + 15) >> 4;
+    const int NC = mlp >> 6, NB = 2 * NC;
+
+    if (wave == MB_CW) {
+        const int srow = lane >> 3, spc = lane & 7;
+        auto issue = [&](int blk) {
+            char* dst = WR + (blk % Ly::NSTAGE) * Ly::WBLK;
+            const int c = blk >> 1;
+            if ((blk & 1) == 0) {
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+                    const bf16* src = W2T + (long)(64 * c + 8 * rg + srow) * D + ((spc ^ srow) << 3);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        __builtin_amdgcn_global_load_lds((gl_vp)(src + kt * 64), (lds_vp)(dst + kt * 8192 + rg * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        const bf16* src = W1T + (long)(64 * j + 8 * rg + srow) * mlp + 64 * c + ((spc ^ srow) << 3);
+                        __builtin_amdgcn_global_load_lds((gl_vp)src, (lds_vp)(dst + j * 8192 + rg * 1024), 16, 0, 0);
+                    }
+                }
+            }
+        };
+        issue(0);
+        issue(1);
+        if (NB > 2) issue(2);
+        __builtin_amdgcn_s_barrier();                                     // B0
+        for (int blk = 0; blk < NB; ++blk) {
+            if (blk + 2 < NB) {
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            } else if (blk + 1 < NB) {
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (blk + 3 < NB) issue(blk + 3);
+        }
+        __builtin_amdgcn_s_barrier();                                     // BE1
+        __builtin_amdgcn_s_barrier();                                     // BE2
+        __builtin_amdgcn_s_barrier();                                     // BE3
+        return;
+    }
+
+    // ---- dx_t and the first u chunk -> LDS; column-sum slab cleared
+    {
+        constexpr int CPR = D / 8;
+        for (int id = tid; id < 48 * CPR; id += 64 * MB_CW) {
+            const int r = id / CPR, c = id % CPR;
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (r < n) v = *reinterpret_cast<const uint4*>(dxt + (row0 + r) * D + c * 8);
+            *reinterpret_cast<uint4*>(XN + r * Ly::XN_PITCH + c * 16) = v;
+        }
+        for (int id = tid; id < 3 * mlp; id += 64 * MB_CW) CS[id] = 0.f;
+    }
+    const int ur = tid >> 3, uc = tid & 7;                                // u chunk loader: thread -> (row, 16-byte piece), tid < 384
+    uint4 u_next = uint4{0u, 0u, 0u, 0u};
+    if (tid < 384 && ur < n) u_next = *reinterpret_cast<const uint4*>(u + (row0 + ur) * mlp + uc * 8);
+    if (tid < 384) *reinterpret_cast<uint4*>(HC + ur * Ly::HC_PITCH + uc * 16) = u_next;          // US[0]
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B0
+
+    const int ct = wave & 3, rt = wave >> 2;
+    f32x4 yacc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < NC; ++c) {
+        char* US = HC + (c & 1) * 2 * Ly::HC_BYTES;
+        char* DS = US + Ly::HC_BYTES;
+        if (c + 1 < NC && tid < 384 && ur < n) u_next = *reinterpret_cast<const uint4*>(u + (row0 + ur) * mlp + 64 * (c + 1) + uc * 8);
+        __builtin_amdgcn_s_barrier();                                     // W2^T chunk c landed (block 2c); u chunk c visible
+        if (rt < RT) {
+            const char* Wb = WR + ((2 * c) % Ly::NSTAGE) * Ly::WBLK;
+            const int wrow = 16 * ct + li;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                Frag<bf16> fw, fa;
+                fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+                fa.v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
+                acc = mma16(fa, fw, acc);
+            }
+            float csum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (16 * rt + 4 * g + r) * Ly::HC_PITCH + (16 * ct + li) * 2;
+                const float uv = (float)*reinterpret_cast<const bf16*>(US + off);
+                const bf16 db_ = (bf16)(acc[r] * gelu_grad_f(uv));
+                *reinterpret_cast<bf16*>(DS + off) = db_;
+                csum += (float)db_;
+            }
+            csum += __shfl_xor(csum, 16, 64);
+            csum += __shfl_xor(csum, 32, 64);
+            if (g == 0) CS[rt * mlp + 64 * c + 16 * ct + li] = csum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // du chunk visible; W1^T chunk c landed (block 2c + 1)
+        for (int id = tid; id < n * 8; id += 64 * MB_CW) {                // du chunk -> global, 128-byte row segments
+            const int r = id >> 3, cc = id & 7;
+            *reinterpret_cast<uint4*>(du_out + (row0 + r) * mlp + 64 * c + cc * 8) = *reinterpret_cast<const uint4*>(DS + r * Ly::HC_PITCH + cc * 16);
+        }
+        if (rt < RT) {
+            const char* Wb = WR + ((2 * c + 1) % Ly::NSTAGE) * Ly::WBLK;
+            Frag<bf16> fa[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8*>(DS + (16 * rt + li) * Ly::HC_PITCH + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int rw = 16 * (ct + 4 * j) + li;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    Frag<bf16> fw;
+                    fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
+                    yacc[j] = mma16(fa[ks], fw, yacc[j]);
+                }
+            }
+        }
+        // u chunk c + 1 into the other buffer (last read two barriers ago)
+        if (c + 1 < NC && tid < 384) *reinterpret_cast<uint4*>(HC + ((c + 1) & 1) * 2 * Ly::HC_BYTES + ur * Ly::HC_PITCH + uc * 16) = u_next;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                         // BE1: ring free, all column sums written
+    float* Y = reinterpret_cast<float*>(WR);
+    constexpr int YLD = Ly::Y_PITCH / 4;
+    if (rt < RT) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * rt + 4 * g + r) * YLD + 16 * (ct + 4 * j) + li] = yacc[j][r];
+    }
+    for (int id = tid; id < mlp; id += 64 * MB_CW) cs_part[(long)b * mlp + id] = (CS[id] + CS[mlp + id]) + CS[2 * mlp + id];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // BE2: dxn2 complete
+    // ---- LN2 backward, row = 4 wave + g on 16 lanes; partial sums over the wave's 4 rows -> LP[wave][3][D]
+    float* LP = reinterpret_cast<float*>(smem);                           // 12 x 3 x D floats (XN + HC are free now)
+    {
+        const int r = 4 * wave + g;
+        const bool ok = r < n;
+        f32x4 xh[KT], dy[KT];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = ok ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (xh[c][0] + xh[c][1]) + (xh[c][2] + xh[c][3]);
+        }
+        const float mean = row16_sum_mb(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = xh[c] - mean;
+            q += (xh[c][0] * xh[c][0] + xh[c][1] * xh[c][1]) + (xh[c][2] * xh[c][2] + xh[c][3] * xh[c][3]);
+        }
+        const float rstd = rsqrtf(row16_sum_mb(q) / D + eps);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 gd[KT];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = xh[c] * rstd;
+            dy[c] = ok ? *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gd[c] = dy[c] * *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c));
+            s1 += (gd[c][0] + gd[c][1]) + (gd[c][2] + gd[c][3]);
+            const f32x4 t = gd[c] * xh[c];
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        s1 = row16_sum_mb(s1) / D;
+        s2 = row16_sum_mb(s2) / D;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const int col = 4 * (li + 16 * c);
+            f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                rr = (gd[c] - s1 - xh[c] * s2) * rstd + *reinterpret_cast<const f32x4*>(dx + (row0 + r) * D + col);
+                *reinterpret_cast<f32x4*>(dx + (row0 + r) * D + col) = rr;
+                bf16x4 pk;
+                pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
+                *reinterpret_cast<bf16x4*>(dx1t_out + (row0 + r) * D + col) = pk;
+            }
+            f32x4 pg = dy[c] * xh[c], pb = dy[c], pc = rr;                // sums over the wave's 4 rows (lanes that differ in g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pg[e] += __shfl_xor(pg[e], 16, 64); pg[e] += __shfl_xor(pg[e], 32, 64);
+                pb[e] += __shfl_xor(pb[e], 16, 64); pb[e] += __shfl_xor(pb[e], 32, 64);
+                pc[e] += __shfl_xor(pc[e], 16, 64); pc[e] += __shfl_xor(pc[e], 32, 64);
+            }
+            if (g == 0) {
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 0) * D + col) = pg;
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 1) * D + col) = pb;
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 2) * D + col) = pc;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // BE3
+    for (int id = tid; id < 3 * D; id += 64 * MB_CW) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MB_CW; ++w) s += LP[w * 3 * D + id];
+        ln_part[(long)b * 3 * D + id] = s;
+    }
+}
+
 }  // namespace
 
 int m3l_mlp_block_supported(int dtype, int D, int mlp, int n) {
     return m3l_attn_block_supported(dtype, D, D / 64, n, 1) && mlp % 64 == 0 && mlp >= 64;
+}
+
+// LDS of the backward: the forward layout + [3][mlp] floats of column sums
+static size_t mb_bwd_lds(int kt, int mlp) { return (kt == 2 ? MbLayout<2>::TOTAL : MbLayout<3>::TOTAL) + (size_t)3 * mlp * sizeof(float); }
+
+int m3l_mlp_block_bwd_supported(int dtype, int D, int mlp, int n) {
+    return m3l_mlp_block_supported(dtype, D, mlp, n) && mb_bwd_lds(D / 64, mlp) <= 160 * 1024;
+}
+
+int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u,
+                      const void* w2T, const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st) {
+    static int inited_mlp = 0;
+    M3L_CHECK(D == 128 || D == 192, "mlp_block_bwd: D=%d unsupported", D);
+    const size_t lds = mb_bwd_lds(D / 64, mlp);
+    if (inited_mlp != mlp) {
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(3, mlp)));
+        inited_mlp = mlp;
+    }
+    ProfScope prof("mlp_block_bwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
+    if (D == 128)
+        mlp_block_bwd_kernel<2><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T,
+                                                           eps, n, mlp, (bf16*)du, (bf16*)dx1t, cs_part, ln_part);
+    else
+        mlp_block_bwd_kernel<3><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T,
+                                                           eps, n, mlp, (bf16*)du, (bf16*)dx1t, cs_part, ln_part);
+    M3L_LAUNCH_CHECK();
+    return 0;
 }
 
 int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2,

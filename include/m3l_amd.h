@@ -50,10 +50,11 @@ int m3l_version(void);
 int m3l_last_error(char* buf, size_t n);
 /* experimental: run the LayerNorms inside the epilogue of the neighbouring GEMM (returns the previous setting; default off) */
 int m3l_set_rowln(int enable);
-/* fused attention block (LN1 + QKV + attention + out-proj + residual + LN2 in one launch) for short sequences: bf16, dim 128 / 192,
- * heads = dim / 64, n <= 64 — on by default (env M3L_ATTN_BLOCK=0 disables); returns the previous setting.  Writes the same
- * activations as the unfused kernels. */
-int m3l_set_attn_block(int enable);
+/* fused per-sample block kernels for short sequences (bf16, dim 128 / 192, heads = dim / 64, n <= 48): mode 0 = off, 1 (default) =
+ * forward attention block (LN1 + QKV + attention + out-proj + residual + LN2) + forward / backward MLP blocks, 3 = also the
+ * attention backward block (correct, measured slower in the full step); env M3L_ATTN_BLOCK sets the initial mode.  Returns the
+ * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
+int m3l_set_attn_block(int mode);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.

@@ -327,11 +327,445 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
 
 int g_ab_state = 0;   // 0 = unknown, 1 = on, -1 = off
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the attention half of a short-sequence layer, dgrad chain only (weight gradients stay with the grouped TN GEMM on the
+// side stream, which reads dqkv written here together with the saved xn1, o and the incoming dx1_t):
+//     dO   = dx1_t Wo                                         (per head: one 64-row block of Wo^T)
+//     dq, dk, dv = attention backward (q, k, v, o, dO, lse)   per head, 3 + 3 waves (dQ by query tile, dK/dV by key tile)
+//     dxn1 = dqkv Wqkv                                         accumulated over the 3 H column blocks of Wqkv^T, fp32, stays on chip
+//     dx   = dx1 + LN1-backward(dxn1; x, gamma1)               + compute-type copy + [3 D] partials (dgamma1 | dbeta1 | colsum dx)
+// One head at a time: its q / k / v / o / dO tiles (48 x 64 each) are the only attention state in LDS; the weight ring carries, per
+// head, the Wo^T block and the three Wqkv^T blocks of that head's q, k and v columns.
+template <int KT> struct AbBwdLayout {
+    static constexpr int D = 64 * KT;
+    static constexpr int A_PITCH = D * 2 + 16;
+    static constexpr int T_PITCH = 64 * 2 + 16;           // 144 B: k-contiguous b128 reads and transpose reads are both conflict-free
+    static constexpr int Y_PITCH = D * 4 + 16;
+    static constexpr int A_BYTES = 48 * A_PITCH;          // dx1_t
+    static constexpr int T_BYTES = 48 * T_PITCH;          // one 48 x 64 tile
+    static constexpr int NT = 8;                          // q, k, v, o, dO, dq, dk, dv
+    static constexpr int WBLK = KT * 64 * 128;
+    static constexpr int NSTAGE = 3;
+    static constexpr int STATS = 2 * 48 * 4;              // lse, Dsum
+    static constexpr int TOTAL = A_BYTES + NT * T_BYTES + STATS + NSTAGE * WBLK;
+    static_assert(48 * Y_PITCH <= NSTAGE * WBLK, "dxn1 staging reuses the ring");
+    static_assert(AB_CW * 3 * D * 4 <= A_BYTES + NT * T_BYTES, "LayerNorm partials reuse the tile region");
+};
+
+template <int KT>
+__global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
+    const bf16* __restrict__ dx1t, const float* __restrict__ dres, const float* __restrict__ x, const float* __restrict__ ln1_w,
+    const bf16* __restrict__ qkv, const bf16* __restrict__ o, const float* __restrict__ lse, const bf16* __restrict__ WoT,
+    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+    float* __restrict__ ln_part) {
+    using Ly = AbBwdLayout<KT>;
+    constexpr int D = Ly::D, H = KT, KSTEPS = 2 * KT, NB = 4 * KT, NDMA = 8 * KT, TP = Ly::T_PITCH, TLD = TP / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A0 = smem;
+    char* TQ = A0 + Ly::A_BYTES;
+    char* TK = TQ + Ly::T_BYTES;
+    char* TV = TK + Ly::T_BYTES;
+    char* TO = TV + Ly::T_BYTES;
+    char* TDO = TO + Ly::T_BYTES;
+    char* TDQ = TDO + Ly::T_BYTES;
+    char* TDK = TDQ + Ly::T_BYTES;
+    char* TDV = TDK + Ly::T_BYTES;
+    float* LS = reinterpret_cast<float*>(TDV + Ly::T_BYTES);
+    float* DSUM = LS + 48;
+    char* WR = reinterpret_cast<char*>(DSUM + 48);
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* gl_vp;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x;
+    const long row0 = (long)b * n;
+    const int RT = (n + 15) >> 4;
+
+    if (wave == AB_CW) {
+        // ------------------------------------------------------------------ DMA wave: per head Wo^T rows 64h.., then the Wqkv^T column
+        // blocks of q_h, k_h, v_h (columns 64h, D + 64h, 2D + 64h of the [D][3D] matrix)
+        const int srow = lane >> 3, spc = lane & 7;
+        auto issue = [&](int blk) {
+            char* dst = WR + (blk % Ly::NSTAGE) * Ly::WBLK;
+            const int h = blk >> 2, kind = blk & 3;
+            if (kind == 0) {
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+                    const bf16* src = WoT + (long)(64 * h + 8 * rg + srow) * D + ((spc ^ srow) << 3);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        __builtin_amdgcn_global_load_lds((gl_vp)(src + kt * 64), (lds_vp)(dst + kt * 8192 + rg * 1024), 16, 0, 0);
+                }
+            } else {
+                const int col0 = (kind - 1) * D + 64 * h;
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        const bf16* src = WqkvT + (long)(64 * j + 8 * rg + srow) * 3 * D + col0 + ((spc ^ srow) << 3);
+                        __builtin_amdgcn_global_load_lds((gl_vp)src, (lds_vp)(dst + j * 8192 + rg * 1024), 16, 0, 0);
+                    }
+                }
+            }
+        };
+        issue(0);
+        issue(1);
+        __builtin_amdgcn_s_barrier();                                     // B0
+        for (int blk = 0; blk < NB; ++blk) {
+            if ((blk & 3) == 1) {                                         // X1, X2, X3 of this head (between its first and second block)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (blk + 1 < NB) {
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                 // R_blk
+            if (blk + 2 < NB) issue(blk + 2);
+        }
+        __builtin_amdgcn_s_barrier();                                     // BE1
+        __builtin_amdgcn_s_barrier();                                     // BE2
+        __builtin_amdgcn_s_barrier();                                     // BE3
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    // tile loader: 4 tiles (q, k, v, o) x 48 rows x 8 pieces of 16 bytes = 1536 pieces, 2 per thread
+    const int pr0 = tid >> 3, pc0 = tid & 7;                              // piece (row, 16-byte column) for tid < 384; tiles 2 * (tid / 384) + {0, 1}
+    const int lrow = pr0 % 48, lt0 = (pr0 / 48) * 2;                      // lt0 in {0, 2}: this thread loads tiles lt0 and lt0 + 1
+    auto tile_src = [&](int t, int h) -> const bf16* {                    // t: 0 q, 1 k, 2 v, 3 o
+        return t < 3 ? qkv + (row0 + lrow) * 3 * D + t * D + 64 * h + pc0 * 8 : o + (row0 + lrow) * D + 64 * h + pc0 * 8;
+    };
+    uint4 nx0 = uint4{0u, 0u, 0u, 0u}, nx1 = nx0;
+    if (lrow < n) {
+        nx0 = *reinterpret_cast<const uint4*>(tile_src(lt0, 0));
+        nx1 = *reinterpret_cast<const uint4*>(tile_src(lt0 + 1, 0));
+    }
+    {
+        constexpr int CPR = D / 8;
+        for (int id = tid; id < 48 * CPR; id += 64 * AB_CW) {
+            const int r = id / CPR, c = id % CPR;
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (r < n) v = *reinterpret_cast<const uint4*>(dx1t + (row0 + r) * D + c * 8);
+            *reinterpret_cast<uint4*>(A0 + r * Ly::A_PITCH + c * 16) = v;
+        }
+    }
+    *reinterpret_cast<uint4*>(TQ + lt0 * Ly::T_BYTES + lrow * TP + pc0 * 16) = nx0;
+    *reinterpret_cast<uint4*>(TQ + (lt0 + 1) * Ly::T_BYTES + lrow * TP + pc0 * 16) = nx1;
+    if (tid < 48) LS[tid] = tid < n ? lse[((long)b * H + 0) * n + tid] : INFINITY;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // B0
+
+    const int ct = wave & 3, rt = wave >> 2;
+    f32x4 yacc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntile = (n + 31) >> 5;
+
+    for (int h = 0; h < H; ++h) {
+        float ls_next = INFINITY;
+        if (h + 1 < H) {                                                  // next head's tiles and lse on their way (registers)
+            if (lrow < n) {
+                nx0 = *reinterpret_cast<const uint4*>(tile_src(lt0, h + 1));
+                nx1 = *reinterpret_cast<const uint4*>(tile_src(lt0 + 1, h + 1));
+            }
+            if (tid < n) ls_next = lse[((long)b * H + h + 1) * n + tid];
+        }
+        // ---- dO_h = dx1_t Wo[:, head h]: block 4h
+        __builtin_amdgcn_s_barrier();                                     // R(4h)
+        if (rt < RT) {
+            const char* Wb = WR + ((4 * h) % Ly::NSTAGE) * Ly::WBLK;
+            const int wrow = 16 * ct + li;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                Frag<bf16> fw, fa;
+                fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+                fa.v = *reinterpret_cast<const bf16x8*>(A0 + (16 * rt + li) * Ly::A_PITCH + (ks * 32 + 8 * g) * 2);
+                acc = mma16(fa, fw, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(TDO + (16 * rt + 4 * g + r) * TP + (16 * ct + li) * 2) = (bf16)acc[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // X1: dO_h visible
+        // ---- Dsum[q] = sum_d dO[q, d] o[q, d]: 8 threads per query
+        if (tid < 384) {
+            const int q = tid >> 3, part = tid & 7;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(TDO + q * TP + part * 16);
+            const bf16x8 c = *reinterpret_cast<const bf16x8*>(TO + q * TP + part * 16);
+            float sdo = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sdo += (float)a[j] * (float)c[j];
+            sdo += __shfl_xor(sdo, 1, 64);
+            sdo += __shfl_xor(sdo, 2, 64);
+            sdo += __shfl_xor(sdo, 4, 64);
+            if (part == 0) DSUM[q] = q < n ? sdo : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // X2: Dsum visible
+        if (wave < RT) {
+            // ---- dQ for query tile `wave` (lane li = query): S^T = K Q^T, dP^T = V dO^T, dS^T -> operand, dQ^T += K^T dS^T
+            const int q = 16 * wave + li;
+            Frag<bf16> fq[2], fdo[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fq[ks].v = *reinterpret_cast<const bf16x8*>(TQ + q * TP + (ks * 32 + 8 * g) * 2);
+                fdo[ks].v = *reinterpret_cast<const bf16x8*>(TDO + q * TP + (ks * 32 + 8 * g) * 2);
+            }
+            const float Dq = DSUM[q], lq = LS[q];
+            f32x4 dq[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < ntile; ++kt) {
+                const bool hi_ok = 32 * kt + 16 < 16 * RT;
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (t == 0 || hi_ok) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            Frag<bf16> fk, fv;
+                            fk.v = *reinterpret_cast<const bf16x8*>(TK + (32 * kt + 16 * t + li) * TP + (ks * 32 + 8 * g) * 2);
+                            fv.v = *reinterpret_cast<const bf16x8*>(TV + (32 * kt + 16 * t + li) * TP + (ks * 32 + 8 * g) * 2);
+                            sc = mma16(fk, fq[ks], sc);
+                            dp = mma16(fv, fdo[ks], dp);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 32 + 16 * t + 4 * g + r;
+                        const float p = (key < n) ? __expf(sc[r] * AB_SCALE - lq) : 0.f;
+                        ds[t][r] = p * (dp[r] - Dq) * AB_SCALE;
+                    }
+                }
+                const Frag<bf16> fds = acc_to_frag<bf16>(ds[0], ds[1]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int q4 = li >> 2, p4 = li & 3;
+                    const bf16* kp = reinterpret_cast<const bf16*>(TK) + (32 * kt + 4 * g + q4) * TLD + 16 * d + 4 * p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)kp);
+                    bf16x4 hi;
+                    hi[0] = hi[1] = hi[2] = hi[3] = (bf16)0.f;
+                    if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(kp + 16 * TLD));
+                    Frag<bf16> fkT;
+                    fkT.v[0] = lo[0]; fkT.v[1] = lo[1]; fkT.v[2] = lo[2]; fkT.v[3] = lo[3];
+                    fkT.v[4] = hi[0]; fkT.v[5] = hi[1]; fkT.v[6] = hi[2]; fkT.v[7] = hi[3];
+                    dq[d] = mma16(fkT, fds, dq[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 pk;
+                pk[0] = (bf16)dq[d][0]; pk[1] = (bf16)dq[d][1]; pk[2] = (bf16)dq[d][2]; pk[3] = (bf16)dq[d][3];
+                if (q >= n) pk[0] = pk[1] = pk[2] = pk[3] = (bf16)0.f;
+                *reinterpret_cast<bf16x4*>(TDQ + q * TP + (16 * d + 4 * g) * 2) = pk;
+            }
+        } else if (wave < 2 * RT) {
+            // ---- dK / dV for key tile `wave - RT` (lane li = key): S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+            const int key = 16 * (wave - RT) + li;
+            Frag<bf16> fk[2], fv[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fk[ks].v = *reinterpret_cast<const bf16x8*>(TK + key * TP + (ks * 32 + 8 * g) * 2);
+                fv[ks].v = *reinterpret_cast<const bf16x8*>(TV + key * TP + (ks * 32 + 8 * g) * 2);
+            }
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int qt = 0; qt < ntile; ++qt) {
+                const bool hi_ok = 32 * qt + 16 < 16 * RT;
+                f32x4 pp[2], ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (t == 0 || hi_ok) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            Frag<bf16> fa, fg;
+                            fa.v = *reinterpret_cast<const bf16x8*>(TQ + (32 * qt + 16 * t + li) * TP + (ks * 32 + 8 * g) * 2);
+                            fg.v = *reinterpret_cast<const bf16x8*>(TDO + (32 * qt + 16 * t + li) * TP + (ks * 32 + 8 * g) * 2);
+                            sc = mma16(fa, fk[ks], sc);
+                            dp = mma16(fg, fv[ks], dp);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = 32 * qt + 16 * t + 4 * g + r;
+                        const bool live = key < n && ql < n;
+                        const float pv = live ? __expf(sc[r] * AB_SCALE - LS[live ? ql : 0]) : 0.f;
+                        pp[t][r] = pv;
+                        ds[t][r] = live ? pv * (dp[r] - DSUM[ql]) * AB_SCALE : 0.f;
+                    }
+                }
+                const Frag<bf16> fp = acc_to_frag<bf16>(pp[0], pp[1]);
+                const Frag<bf16> fds = acc_to_frag<bf16>(ds[0], ds[1]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int q4 = li >> 2, p4 = li & 3;
+                    const int roff = (32 * qt + 4 * g + q4) * TLD + 16 * d + 4 * p4;
+                    const bf16* gp = reinterpret_cast<const bf16*>(TDO) + roff;
+                    const bf16* qp = reinterpret_cast<const bf16*>(TQ) + roff;
+                    const bf16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)gp);
+                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)qp);
+                    bf16x4 ghi, qhi;
+                    ghi[0] = ghi[1] = ghi[2] = ghi[3] = (bf16)0.f;
+                    qhi = ghi;
+                    if (hi_ok) {
+                        ghi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(gp + 16 * TLD));
+                        qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(qp + 16 * TLD));
+                    }
+                    Frag<bf16> fgT, fqT;
+                    fgT.v[0] = glo[0]; fgT.v[1] = glo[1]; fgT.v[2] = glo[2]; fgT.v[3] = glo[3];
+                    fgT.v[4] = ghi[0]; fgT.v[5] = ghi[1]; fgT.v[6] = ghi[2]; fgT.v[7] = ghi[3];
+                    fqT.v[0] = qlo[0]; fqT.v[1] = qlo[1]; fqT.v[2] = qlo[2]; fqT.v[3] = qlo[3];
+                    fqT.v[4] = qhi[0]; fqT.v[5] = qhi[1]; fqT.v[6] = qhi[2]; fqT.v[7] = qhi[3];
+                    dv[d] = mma16(fgT, fp, dv[d]);
+                    dk[d] = mma16(fqT, fds, dk[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 kk, vv;
+                kk[0] = (bf16)dk[d][0]; kk[1] = (bf16)dk[d][1]; kk[2] = (bf16)dk[d][2]; kk[3] = (bf16)dk[d][3];
+                vv[0] = (bf16)dv[d][0]; vv[1] = (bf16)dv[d][1]; vv[2] = (bf16)dv[d][2]; vv[3] = (bf16)dv[d][3];
+                if (key >= n) { kk[0] = kk[1] = kk[2] = kk[3] = (bf16)0.f; vv = kk; }
+                *reinterpret_cast<bf16x4*>(TDK + key * TP + (16 * d + 4 * g) * 2) = kk;
+                *reinterpret_cast<bf16x4*>(TDV + key * TP + (16 * d + 4 * g) * 2) = vv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // X3: dq / dk / dv of this head visible; q, k, v, o, lse free
+        // next head's tiles into place; this head's dq | dk | dv out to global (128-byte row segments)
+        if (h + 1 < H) {
+            *reinterpret_cast<uint4*>(TQ + lt0 * Ly::T_BYTES + lrow * TP + pc0 * 16) = nx0;
+            *reinterpret_cast<uint4*>(TQ + (lt0 + 1) * Ly::T_BYTES + lrow * TP + pc0 * 16) = nx1;
+            if (tid < 48) LS[tid] = ls_next;
+        }
+        for (int id = tid; id < n * 24; id += 64 * AB_CW) {
+            const int t = id / (n * 8), rc = id % (n * 8), r = rc >> 3, cc = rc & 7;
+            *reinterpret_cast<uint4*>(dqkv_out + (row0 + r) * 3 * D + t * D + 64 * h + cc * 8) =
+                *reinterpret_cast<const uint4*>(TDQ + t * Ly::T_BYTES + r * TP + cc * 16);
+        }
+        // ---- dxn1 += dq_h Wqkv[q_h cols] + dk_h Wqkv[k_h cols] + dv_h Wqkv[v_h cols]: blocks 4h + 1 .. 4h + 3
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            __builtin_amdgcn_s_barrier();                                 // R(4h + 1 + t)
+            if (rt < RT) {
+                const char* Wb = WR + ((4 * h + 1 + t) % Ly::NSTAGE) * Ly::WBLK;
+                const char* Ts = TDQ + t * Ly::T_BYTES;
+                Frag<bf16> fa[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8*>(Ts + (16 * rt + li) * TP + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const int rw = 16 * (ct + 4 * j) + li;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        Frag<bf16> fw;
+                        fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
+                        yacc[j] = mma16(fa[ks], fw, yacc[j]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                         // BE1: ring free
+    float* Y = reinterpret_cast<float*>(WR);
+    constexpr int YLD = Ly::Y_PITCH / 4;
+    if (rt < RT) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * rt + 4 * g + r) * YLD + 16 * (ct + 4 * j) + li] = yacc[j][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // BE2: dxn1 complete
+    // ---- LN1 backward, row = 4 wave + g on 16 lanes
+    float* LP = reinterpret_cast<float*>(smem);
+    {
+        const int r = 4 * wave + g;
+        const bool ok = r < n;
+        f32x4 xh[KT], dy[KT], gd[KT];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = ok ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (xh[c][0] + xh[c][1]) + (xh[c][2] + xh[c][3]);
+        }
+        const float mean = row16_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = xh[c] - mean;
+            q += (xh[c][0] * xh[c][0] + xh[c][1] * xh[c][1]) + (xh[c][2] * xh[c][2] + xh[c][3] * xh[c][3]);
+        }
+        const float rstd = rsqrtf(row16_sum(q) / D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            xh[c] = xh[c] * rstd;
+            dy[c] = ok ? *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gd[c] = dy[c] * *reinterpret_cast<const f32x4*>(ln1_w + 4 * (li + 16 * c));
+            s1 += (gd[c][0] + gd[c][1]) + (gd[c][2] + gd[c][3]);
+            const f32x4 t = gd[c] * xh[c];
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        s1 = row16_sum(s1) / D;
+        s2 = row16_sum(s2) / D;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const int col = 4 * (li + 16 * c);
+            f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                rr = (gd[c] - s1 - xh[c] * s2) * rstd + *reinterpret_cast<const f32x4*>(dres + (row0 + r) * D + col);
+                *reinterpret_cast<f32x4*>(dx_out + (row0 + r) * D + col) = rr;
+                if (dxt_out) {
+                    bf16x4 pk;
+                    pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
+                    *reinterpret_cast<bf16x4*>(dxt_out + (row0 + r) * D + col) = pk;
+                }
+            }
+            f32x4 pg = dy[c] * xh[c], pb = dy[c], pc = rr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pg[e] += __shfl_xor(pg[e], 16, 64); pg[e] += __shfl_xor(pg[e], 32, 64);
+                pb[e] += __shfl_xor(pb[e], 16, 64); pb[e] += __shfl_xor(pb[e], 32, 64);
+                pc[e] += __shfl_xor(pc[e], 16, 64); pc[e] += __shfl_xor(pc[e], 32, 64);
+            }
+            if (g == 0) {
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 0) * D + col) = pg;
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 1) * D + col) = pb;
+                *reinterpret_cast<f32x4*>(LP + (wave * 3 + 2) * D + col) = pc;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // BE3
+    for (int id = tid; id < 3 * D; id += 64 * AB_CW) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < AB_CW; ++w) sacc += LP[w * 3 * D + id];
+        ln_part[(long)b * 3 * D + id] = sacc;
+    }
+}
+
 }  // namespace
 
-extern "C" int m3l_set_attn_block(int enable) {
-    const int old = g_ab_state == -1 ? 0 : 1;
-    g_ab_state = enable ? 1 : -1;
+// g_ab_state: 0 = unread, -1 = off, otherwise a bit mask: 1 = forward blocks + MLP backward block, 2 = attention backward block too
+extern "C" int m3l_set_attn_block(int mode) {
+    const int old = g_ab_state <= 0 ? 0 : g_ab_state;
+    g_ab_state = mode > 0 ? mode : -1;
     return old;
 }
 
@@ -339,11 +773,17 @@ extern "C" int m3l_set_attn_block(int enable) {
 int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out) {
     if (!g_ab_state) {
         const char* e = getenv("M3L_ATTN_BLOCK");
-        g_ab_state = (e && e[0] == '0') ? -1 : 1;
+        g_ab_state = e ? (atoi(e) > 0 ? atoi(e) : -1) : 1;
     }
-    if (g_ab_state != 1) return 0;
+    if (g_ab_state < 1) return 0;
     return dtype == 1 && project_out && (D == 128 || D == 192) && heads * 64 == D && n >= 1 && n <= 48;
 }
+
+// The attention BACKWARD block is correct (tests run it) but off by default: with one 149 KB workgroup per CU it cannot share a CU
+// with the 64 KB weight-gradient workgroups of the side stream, and once both halves of the backward are fused the per-layer
+// compute-stream time (56 us) drops below the side stream's (65 us) so the weight gradients stop being hidden: 47.8k -> 42.8k
+// samples/s at cfg 2.  M3L_ATTN_BLOCK=3 (or m3l_set_attn_block(3)) enables it.
+int m3l_attn_block_bwd_enabled(void) { return g_ab_state > 0 && (g_ab_state & 2); }
 
 int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
                        const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,
@@ -362,6 +802,28 @@ int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, 
     if (D == 128) AB_LAUNCH(2);
     else AB_LAUNCH(3);
 #undef AB_LAUNCH
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres, const float* x, const float* ln1_w, const void* qkv,
+                       const void* o, const float* lse, const void* woT, const void* wqkvT, float eps, void* dqkv, float* dx_out, void* dxt_out,
+                       float* ln_part, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<3>::TOTAL));
+        inited = 1;
+    }
+    M3L_CHECK(D == 128 || D == 192, "attn_block_bwd: D=%d unsupported", D);
+    ProfScope prof("attn_block_bwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64, st);
+#define ABB_LAUNCH(KT)                                                                                                               \
+    attn_block_bwd_kernel<KT><<<B, AB_THREADS, AbBwdLayout<KT>::TOTAL, st>>>((const bf16*)dx1t, dres, x, ln1_w, (const bf16*)qkv, (const bf16*)o, lse, \
+                                                                            (const bf16*)woT, (const bf16*)wqkvT, eps, n, (bf16*)dqkv, dx_out,      \
+                                                                            (bf16*)dxt_out, ln_part)
+    if (D == 128) ABB_LAUNCH(2);
+    else ABB_LAUNCH(3);
+#undef ABB_LAUNCH
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -119,6 +119,7 @@ int m3l_gemm_nt_colsum_rows(int M, int N);   // number of partial rows written t
 
 // fused LN1 + QKV + attention + out-proj + residual + LN2 for short sequences (attn_block.hip)
 int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out);
+int m3l_attn_block_bwd_enabled(void);
 int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
                        const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,
                        float* x1, void* xn2, hipStream_t st);
@@ -130,6 +131,10 @@ int m3l_mlp_block_bwd_supported(int dtype, int D, int mlp, int n);
 // dgrad chain of the feed-forward half + LN2 backward; cs_part [B][mlp] and ln_part [B][3 D] are per-sample partial rows
 int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u,
                       const void* w2T, const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st);
+// dgrad chain of the attention half + LN1 backward (attn_block.hip); ln_part [B][3 D] per-sample partial rows; dxt_out may be null
+int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres, const float* x, const float* ln1_w, const void* qkv,
+                       const void* o, const float* lse, const void* woT, const void* wqkvT, float eps, void* dqkv, float* dx_out, void* dxt_out,
+                       float* ln_part, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

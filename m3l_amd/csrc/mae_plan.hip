@@ -618,7 +618,19 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
                 return 1;
         }
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
+        const bool attn_block = mlp_block && m3l_attn_block_bwd_enabled() && m3l_attn_block_supported(dt, D, c->heads, n, c->project_out);
+        float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
+        float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
+        if (attn_block) {
+            // short sequences: dO, the attention backward, dxn1 and the LN1 backward in one launch.  It writes dx_t[cur^1] (the next
+            // layer's operand set), which the side-stream wgrad of layer l+1 may still be reading.
+            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
+            if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
+                                   dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+                return 1;
+        }
         const void* d_o = w.dx1_t[cur];
+        if (!attn_block) {
         if (c->project_out) {
             e = epi0(HD);
             e.out_t = w.d_o;
@@ -626,6 +638,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             d_o = w.d_o;
         }
         if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv[cur], B, n, c->heads, st)) return 1;
+        }
         // ---- all weight gradients of the layer: ONE grouped TN launch + one reduce, on the side stream, overlapping the
         // rest of this layer's and the next layer's dgrad chain (these kernels alone do not fill 256 CUs at M = B*48)
         {
@@ -645,8 +658,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         // the last kernel of this layer writes dx_t[cur^1] (and the next layer then du/dx1_t/dqkv[cur^1]): the wgrad of layer
         // l+1, which reads that set, must be done
-        float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
-        float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
+        if (attn_block) continue;
         if (fuse) {
             if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
             RowLnEpi r;

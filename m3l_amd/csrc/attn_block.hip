@@ -763,19 +763,24 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
 }  // namespace
 
 // g_ab_state: 0 = unread, -1 = off, otherwise a bit mask: 1 = forward blocks + MLP backward block, 2 = attention backward block too
+static int ab_state() {
+    if (!g_ab_state) {
+        const char* e = getenv("M3L_ATTN_BLOCK");
+        g_ab_state = e ? (atoi(e) > 0 ? atoi(e) : -1) : 1;
+    }
+    return g_ab_state;
+}
+// Sets the block-kernel mode (0 = off) and returns the mode that was in effect (environment default resolved), so that
+// `m3l_set_attn_block(m3l_set_attn_block(x))` restores the previous state exactly.
 extern "C" int m3l_set_attn_block(int mode) {
-    const int old = g_ab_state <= 0 ? 0 : g_ab_state;
+    const int old = ab_state() < 0 ? 0 : g_ab_state;
     g_ab_state = mode > 0 ? mode : -1;
     return old;
 }
 
 // 1 when the fused attention-block kernel takes this problem
 int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out) {
-    if (!g_ab_state) {
-        const char* e = getenv("M3L_ATTN_BLOCK");
-        g_ab_state = e ? (atoi(e) > 0 ? atoi(e) : -1) : 1;
-    }
-    if (g_ab_state < 1) return 0;
+    if (ab_state() < 1) return 0;
     return dtype == 1 && project_out && (D == 128 || D == 192) && heads * 64 == D && n >= 1 && n <= 48;
 }
 
@@ -783,7 +788,7 @@ int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out
 // with the 64 KB weight-gradient workgroups of the side stream, and once both halves of the backward are fused the per-layer
 // compute-stream time (56 us) drops below the side stream's (65 us) so the weight gradients stop being hidden: 47.8k -> 42.8k
 // samples/s at cfg 2.  M3L_ATTN_BLOCK=3 (or m3l_set_attn_block(3)) enables it.
-int m3l_attn_block_bwd_enabled(void) { return g_ab_state > 0 && (g_ab_state & 2); }
+int m3l_attn_block_bwd_enabled(void) { return ab_state() > 0 && (g_ab_state & 2); }
 
 int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,
                        const float* bo, const float* ln2_w, const float* ln2_b, float eps, void* xn1, void* qkv, void* o, float* lse,

@@ -1,0 +1,162 @@
+"""Full-depth oracle parity of the HEADLINE architectures — exactly what bench.py times, not a cut-down stack:
+
+  * BASELINE cfg 2: ViT-Tiny encoder 192 / 12 layers / 3 heads / mlp 768 + decoder 192 / 4 / 3 / 768, 64x64 RGB + 2 x 32x32 tactile,
+    mask 0.75, B = 16 — fp32 and bf16, the bf16 run with every block-kernel mode (0 = unfused, 1 = default, 3 = + attention backward
+    block) against the fp32 CPU oracle (oracle/vtmae_oracle.py = reference models/pretrain_models.py:146-342);
+  * BASELINE cfg 4 at full depth: 384 / 12 / 6 / 1536 + decoder 192 / 4 / 3, 224x224 + 4 x 64x64, B = 2;
+  * a 10-step loss trajectory through Adam (reference update loop models/ppo_mae.py:262-266), bf16 HIP vs fp32 oracle.
+
+Bounds (BASELINE.json north_star): mask indices bit-exact; loss 1e-4 rel (fp32) / 1e-2 rel (bf16); gradients per parameter and as
+one vector (relative L2) as in test_parity_gpu.py::test_oracle_vit_tiny_shapes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from m3l_amd import VTMAE, VTT  # noqa: E402
+from m3l_amd import _lib as L  # noqa: E402
+from oracle import vtmae_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _build(arch, dt, seed=0):
+    torch.manual_seed(seed)
+    enc = VTT(**arch["enc"])
+    return VTMAE(encoder=enc, compute_dtype=dt, **arch["mae"]).to(DEV)
+
+
+CFG2 = dict(enc=dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=192, depth=12, heads=3, mlp_dim=768),
+            mae=dict(decoder_dim=192, masking_ratio=0.75, decoder_depth=4, decoder_heads=3),
+            ocfg=O.OracleCfg(64, 32, 8, 4, 192, 12, 3, 768, 3, 2, 192, 4, 3, 0.75), hw=(64, 32), k=2)
+CFG4 = dict(enc=dict(image_size=224, tactile_size=64, image_patch_size=16, tactile_patch_size=8, dim=384, depth=12, heads=6, mlp_dim=1536,
+                     num_tactiles=4),
+            mae=dict(decoder_dim=192, masking_ratio=0.75, decoder_depth=4, decoder_heads=3, num_tactiles=4),
+            ocfg=O.OracleCfg(224, 64, 16, 8, 384, 12, 6, 1536, 3, 4, 192, 4, 3, 0.75), hw=(224, 64), k=4)
+
+
+def _data(arch, B, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    hi, ht = arch["hw"]
+    x = {"image": torch.rand(B, 3, hi, hi, generator=g)}
+    for i in range(arch["k"]):
+        x[f"tactile{i + 1}"] = torch.rand(B, 3, ht, ht, generator=g)
+    c = arch["ocfg"]
+    noises = [torch.rand(B, c.n_img, generator=g)] + [torch.rand(B, c.n_tac, generator=g) for _ in range(arch["k"])]
+    return x, noises
+
+
+def _perturb(mae):
+    """LayerNorm gains / biases and Linear biases away from their 1 / 0 initial values, so that every bias / affine path matters."""
+    g = torch.Generator(device="cpu").manual_seed(99)
+    with torch.no_grad():
+        for p in mae.parameters():
+            if p.dim() == 1:
+                p.add_((0.05 * torch.randn(p.shape, generator=g)).to(p.device))
+
+
+class _Oracle:
+    """One oracle run per architecture, shared by the compute-type / block-mode cases."""
+    cache = {}
+
+    @classmethod
+    def get(cls, name, arch, B):
+        if name not in cls.cache:
+            mae = _build(arch, "fp32")
+            _perturb(mae)
+            sd = {k: v.detach().cpu().clone() for k, v in mae.state_dict().items()}
+            x, noises = _data(arch, B, seed=1)
+            P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+            r = O.vtmae_forward(P, arch["ocfg"], x, noises)
+            r["loss"].backward()
+            cls.cache[name] = (sd, x, noises, {k: (v.grad.clone() if v.grad is not None else None) for k, v in P.items()},
+                               float(r["loss"].detach()), r["masked_indices"].clone(), r["unmasked_indices"].clone())
+        return cls.cache[name]
+
+
+def _check(arch, name, B, dt, mode, ltol, gtol, l2tol):
+    sd, x, noises, G, loss_ref, m_ref, u_ref = _Oracle.get(name, arch, B)
+    mae = _build(arch, dt)
+    mae.load_state_dict(sd, strict=True)
+    old = L.lib().m3l_set_attn_block(mode)
+    try:
+        loss = mae({k: v.to(DEV) for k, v in x.items()}, mask_noise=[n.to(DEV) for n in noises])
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        L.lib().m3l_set_attn_block(old)
+    assert torch.equal(mae.last_mask[0].cpu(), m_ref) and torch.equal(mae.last_mask[1].cpu(), u_ref), "mask indices not bit-exact"
+    rel = abs(float(loss.detach()) - loss_ref) / abs(loss_ref)
+    assert rel <= ltol, (dt, mode, float(loss.detach()), loss_ref, rel)
+    num = den = 0.0
+    worst = ("", 0.0)
+    for pname, p in mae.named_parameters():
+        ref = G[pname]
+        if ref is None:
+            assert p.grad is None, pname
+            continue
+        assert p.grad is not None, pname
+        d = p.grad.cpu() - ref
+        err = float(d.abs().max()) / max(1e-7, float(ref.abs().max()))
+        if err > worst[1]:
+            worst = (pname, err)
+        num += float(d.double().square().sum())
+        den += float(ref.double().square().sum())
+    l2 = (num / den) ** 0.5
+    print(f"[fulldepth] {name} {dt} block-mode {mode}: loss rel {rel:.2e}, worst grad {worst[0]} {worst[1]:.2e}, grad rel-L2 {l2:.2e}")
+    assert worst[1] <= gtol, (dt, mode, worst, l2)
+    assert l2 <= l2tol, (dt, mode, l2, worst)
+    return rel, worst, l2
+
+
+@pytest.mark.parametrize("dt,mode", [("fp32", 1), ("bf16", 0), ("bf16", 1), ("bf16", 3)])
+def test_cfg2_full_depth_vs_oracle(dt, mode):
+    if dt == "fp32":
+        _check(CFG2, "cfg2", 16, dt, mode, 1e-4, 2e-3, 1e-4)
+    else:
+        _check(CFG2, "cfg2", 16, dt, mode, 1e-2, 0.15, 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_cfg4_full_depth_vs_oracle(dt):
+    if dt == "fp32":
+        _check(CFG4, "cfg4", 2, dt, 1, 1e-4, 3e-3, 1e-4)
+    else:
+        _check(CFG4, "cfg4", 2, dt, 1, 1e-2, 0.15, 2e-2)
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_cfg2_bf16_trajectory_through_adam(mode):
+    """Ten MAE updates (zero_grad -> loss -> backward -> Adam.step, models/ppo_mae.py:262-266 with lr 1e-4 as :183) on a fixed batch
+    sequence: the bf16 HIP step (fp32 master weights) must track the fp32 CPU oracle's loss at every step within 1e-2."""
+    arch, B, steps = CFG2, 8, 10
+    mae = _build(arch, "bf16", seed=3)
+    sd = {k: v.detach().cpu().clone() for k, v in mae.state_dict().items()}
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    trained = [k for k, _ in mae.named_parameters()]
+    opt_o = torch.optim.Adam([P[k] for k in trained], lr=1e-4)
+    opt_g = torch.optim.Adam(mae.parameters(), lr=1e-4)
+    old = L.lib().m3l_set_attn_block(mode)
+    try:
+        for s in range(steps):
+            x, noises = _data(arch, B, seed=100 + s)
+            opt_o.zero_grad()
+            r = O.vtmae_forward(P, arch["ocfg"], x, noises)
+            r["loss"].backward()
+            opt_o.step()
+            opt_g.zero_grad()
+            loss = mae({k: v.to(DEV) for k, v in x.items()}, mask_noise=[n.to(DEV) for n in noises])
+            loss.backward()
+            opt_g.step()
+            lo, lg = float(r["loss"]), float(loss.detach())
+            assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"])
+            assert abs(lg - lo) <= 1e-2 * abs(lo), (s, lg, lo)
+    finally:
+        L.lib().m3l_set_attn_block(old)
+    # the stepped weights stay close too (Adam's first steps are sign-like: compare the update direction on a large tensor)
+    k = "decoder.layers.0.1.net.1.weight"
+    d_o = (P[k].detach() - sd[k]).flatten()
+    d_g = (dict(mae.named_parameters())[k].detach().cpu() - sd[k]).flatten()
+    cos = float((d_o * d_g).sum() / (d_o.norm() * d_g.norm()))
+    assert cos > 0.9, cos

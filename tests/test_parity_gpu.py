@@ -851,7 +851,7 @@ def test_fused_attention_block_matches_unfused(D, heads, n_img_hw, B):
             emb = mae.get_embeddings(x, eval=False).detach().clone()          # all tokens: decoder-length sequences stay unfused
             res[mode] = (float(loss.detach()), emb, {k: p.grad.clone() for k, p in mae.named_parameters() if p.grad is not None})
     finally:
-        L.lib().m3l_set_attn_block(old if old > 0 else 0)
+        L.lib().m3l_set_attn_block(old)
     for mode in (1, 3):
         assert abs(res[mode][0] - res[0][0]) <= 2e-3 * abs(res[0][0]), (mode, res[mode][0], res[0][0])
         assert (res[mode][1] - res[0][1]).abs().max().item() <= 3e-2 * res[0][1].abs().max().item()

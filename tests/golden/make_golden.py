@@ -396,10 +396,77 @@ def run_vtt_dino():
     print("vtt_dino_small: patchtokens", tuple(mk.shape), "pos", tuple(pos.shape))
 
 
+def _ref_layers():
+    """`tactile_ssl.model.layers` of the reference, loaded from its own files: `tactile_ssl/model/__init__.py` pulls torchvision
+    through pretrained.py, so the `tactile_ssl.model` package object is created bare (its __path__ points at the real directory)."""
+    import tactile_ssl  # noqa: F401  imports cleanly
+    if "tactile_ssl.model" not in sys.modules:
+        pkg = types.ModuleType("tactile_ssl.model")
+        pkg.__path__ = [os.path.join(REF, "tactile_ssl", "model")]
+        sys.modules["tactile_ssl.model"] = pkg
+    os.environ["XFORMERS_DISABLED"] = "1"
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return importlib.import_module("tactile_ssl.model.layers.block")
+
+
+def run_block_stack():
+    """The reference's OWN pre-norm transformer block — tactile_ssl/model/layers/block.py:43-114 (`Block.forward`: x + attn(norm1(x)),
+    x + mlp(norm2(x))), attention.py:54-76 (bias-free fused qkv, q|k|v head-major, q scaled by head_dim^-0.5, softmax, proj) and
+    mlp.py:34-40 (fc1, GELU, fc2) — as a 2-layer stack + nn.LayerNorm on random tokens at the MAE's two sequence lengths (48 visible /
+    192 decoder tokens).  It is the same arithmetic as vit-pytorch's Transformer with the parameter names mapped
+    (norm1 -> layers.i.0.norm, attn.qkv -> to_qkv, attn.proj -> to_out.0, norm2 -> net.0, mlp.fc1 -> net.1, mlp.fc2 -> net.4), so this
+    fixture pins the attention / GELU-MLP / LayerNorm kernels and the oracle's `transformer` to reference-held code."""
+    blk = _ref_layers()
+    torch.manual_seed(41)
+    D, heads, depth, ratio = 128, 2, 2, 2.0
+    blocks = torch.nn.ModuleList([blk.Block(dim=D, num_heads=heads, mlp_ratio=ratio, qkv_bias=False) for _ in range(depth)])
+    norm = torch.nn.LayerNorm(D)
+    g = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for p in list(blocks.parameters()) + list(norm.parameters()):
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    out = {"meta": np.array([D, depth, heads, int(D * ratio)], dtype=np.int64)}
+    names = {}
+    for i, b in enumerate(blocks):
+        names.update({f"layers.{i}.0.norm.weight": b.norm1.weight, f"layers.{i}.0.norm.bias": b.norm1.bias,
+                      f"layers.{i}.0.to_qkv.weight": b.attn.qkv.weight, f"layers.{i}.0.to_out.0.weight": b.attn.proj.weight,
+                      f"layers.{i}.0.to_out.0.bias": b.attn.proj.bias, f"layers.{i}.1.net.0.weight": b.norm2.weight,
+                      f"layers.{i}.1.net.0.bias": b.norm2.bias, f"layers.{i}.1.net.1.weight": b.mlp.fc1.weight,
+                      f"layers.{i}.1.net.1.bias": b.mlp.fc1.bias, f"layers.{i}.1.net.4.weight": b.mlp.fc2.weight,
+                      f"layers.{i}.1.net.4.bias": b.mlp.fc2.bias})
+    names.update({"norm.weight": norm.weight, "norm.bias": norm.bias})
+    assert len(names) == len(list(blocks.parameters())) + 2      # every parameter of the stack is mapped (no LayerScale: init_values=None)
+    out.update({"param/" + k: v.detach().numpy().copy() for k, v in names.items()})
+    for n, B in ((48, 3), (192, 2)):
+        x = (torch.randn(B, n, D, generator=g) * 1.5).requires_grad_(True)
+        cot = torch.randn(B, n, D, generator=g)
+        for p in names.values():
+            p.grad = None
+        h = x
+        mids = []
+        for b in blocks:
+            h = b(h)
+            mids.append(h)
+        y = norm(h)
+        (y * cot).sum().backward()
+        out[f"n{n}/x"], out[f"n{n}/cot"], out[f"n{n}/y"] = x.detach().numpy(), cot.numpy(), y.detach().numpy()
+        out[f"n{n}/block0_out"] = mids[0].detach().numpy()
+        out[f"n{n}/dx"] = x.grad.numpy()
+        out.update({f"n{n}/grad/" + k: v.grad.numpy().copy() for k, v in names.items()})
+        print(f"block_stack n={n}: y {tuple(y.shape)} |y| {float(y.abs().mean()):.4f}")
+    np.savez_compressed(os.path.join(HERE, "block_stack.npz"), **out)
+
+
 def main():
     ref = _load_reference()
     if "--ppo-only" in sys.argv:
         run_ppo_like(ref)
+        return
+    if "--block-only" in sys.argv:
+        run_block_stack()
         return
     if "--extractor-only" in sys.argv:
         run_extractor(ref)
@@ -434,6 +501,7 @@ def _main_cases(ref):
              num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=15, with_embeddings=True, early_conv=True)
     run_vt_load(ref)
     run_vtt_dino()
+    run_block_stack()
 
 
 if __name__ == "__main__":

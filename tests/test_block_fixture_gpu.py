@@ -1,0 +1,95 @@
+"""The transformer kernels (LayerNorm, QKV / out-proj / MLP GEMMs, attention, GELU; per-op and fused block kernels) against
+
+  * tests/golden/block_stack.npz — outputs and gradients of the reference's OWN pre-norm block
+    (/root/reference/tactile_ssl/model/layers/block.py:89-114, attention.py:54-76, mlp.py:34-40; written by
+    tests/golden/make_golden.py::run_block_stack from the imported reference classes), and
+  * the CPU oracle at the sequence lengths / widths where the block kernels change code path (partial last tile, one or two key
+    tiles, the short MLP ring), per parameter, for every block mode.
+
+bf16 bounds are relative to the largest element of the reference tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from m3l_amd import Transformer  # noqa: E402
+from m3l_amd import _lib as L  # noqa: E402
+from oracle import vtmae_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _run(tf, x, cot, mode):
+    old = L.lib().m3l_set_attn_block(mode)
+    try:
+        tf.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = tf(xg)
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        L.lib().m3l_set_attn_block(old)
+    return y.detach().cpu(), xg.grad.cpu(), {k: p.grad.cpu().clone() for k, p in tf.named_parameters()}
+
+
+def _relmax(a, ref):
+    return float((a - ref).abs().max()) / max(1e-7, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("n", [48, 192])
+@pytest.mark.parametrize("dt,mode", [("fp32", 1), ("bf16", 0), ("bf16", 1), ("bf16", 3)])
+def test_transformer_vs_reference_held_block(golden_dir, n, dt, mode):
+    z = np.load(os.path.join(golden_dir, "block_stack.npz"))
+    D, depth, heads, mlp = [int(v) for v in z["meta"]]
+    tf = Transformer(D, depth, heads, 64, mlp)
+    tf.load_state_dict({k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    tf.compute_dtype = dt
+    tf = tf.to(DEV)
+    x, cot = torch.tensor(z[f"n{n}/x"]).to(DEV), torch.tensor(z[f"n{n}/cot"]).to(DEV)
+    y, dx, grads = _run(tf, x, cot, mode)
+    ytol, gtol = (1e-5, 1e-5) if dt == "fp32" else (1e-2, 2e-2)
+    ey = _relmax(y, torch.tensor(z[f"n{n}/y"]))
+    edx = _relmax(dx, torch.tensor(z[f"n{n}/dx"]))
+    worst = max(((k, _relmax(g, torch.tensor(z[f"n{n}/grad/{k}"]))) for k, g in grads.items()), key=lambda t: t[1])
+    print(f"\n[block_stack] n={n} {dt} mode {mode}: y {ey:.2e} dx {edx:.2e} worst grad {worst[0]} {worst[1]:.2e}")
+    assert ey <= ytol and edx <= gtol and worst[1] <= gtol, (ey, edx, worst)
+
+
+@pytest.mark.parametrize("D,heads,mlp,n,B", [(192, 3, 768, 20, 5), (192, 3, 768, 40, 3), (192, 3, 64, 48, 4), (128, 2, 64, 33, 3),
+                                             (128, 2, 256, 17, 6), (192, 3, 384, 1, 7), (128, 2, 128, 47, 2)])
+def test_block_kernels_edge_lengths(D, heads, mlp, n, B):
+    """Sequence lengths that take the block kernels' other paths — a partial last 16-row tile, n in 17..32 (one key tile), n in
+    33..47 (second key tile half present), n = 1 — and mlp = 64 (two-block MLP ring): modes 1 and 3 per parameter against the fp32
+    oracle AND against the unfused bf16 kernels (mode 0)."""
+    torch.manual_seed(D + n)
+    tf = Transformer(D, 2, heads, 64, mlp)
+    g = torch.Generator().manual_seed(n)
+    with torch.no_grad():
+        for p in tf.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    tf.compute_dtype = "bf16"
+    tf = tf.to(DEV)
+    x = (torch.randn(B, n, D, generator=g) * 1.5).to(DEV)
+    cot = torch.randn(B, n, D, generator=g).to(DEV)
+    P = {"t." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in tf.state_dict().items()}
+    xo = x.cpu().clone().requires_grad_(True)
+    yo = O.transformer(xo, P, "t.", 2, heads, 64)
+    (yo * cot.cpu()).sum().backward()
+    res = {m: _run(tf, x, cot, m) for m in (0, 1, 3)}
+    for m in (0, 1, 3):
+        y, dx, grads = res[m]
+        ey, edx = _relmax(y, yo.detach()), _relmax(dx, xo.grad)
+        worst = max(((k, _relmax(gr, P["t." + k].grad)) for k, gr in grads.items()), key=lambda t: t[1])
+        print(f"\n[edge] D={D} mlp={mlp} n={n} mode {m} vs oracle: y {ey:.2e} dx {edx:.2e} worst {worst[0]} {worst[1]:.2e}")
+        assert ey <= 5e-3 and edx <= 1e-2 and worst[1] <= 2e-2, (m, ey, edx, worst)
+    for m in (1, 3):
+        y, dx, grads = res[m]
+        y0, dx0, g0 = res[0]
+        ey, edx = _relmax(y, y0), _relmax(dx, dx0)
+        worst = max(((k, _relmax(gr, g0[k])) for k, gr in grads.items()), key=lambda t: t[1])
+        print(f"\n[edge] D={D} mlp={mlp} n={n} mode {m} vs unfused: y {ey:.2e} dx {edx:.2e} worst {worst[0]} {worst[1]:.2e}")
+        assert ey <= 5e-3 and edx <= 1e-2 and worst[1] <= 2e-2, (m, ey, edx, worst)

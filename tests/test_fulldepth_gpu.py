@@ -104,7 +104,7 @@ def _check(arch, name, B, dt, mode, ltol, gtol, l2tol):
         num += float(d.double().square().sum())
         den += float(ref.double().square().sum())
     l2 = (num / den) ** 0.5
-    print(f"[fulldepth] {name} {dt} block-mode {mode}: loss rel {rel:.2e}, worst grad {worst[0]} {worst[1]:.2e}, grad rel-L2 {l2:.2e}")
+    print(f"\n[fulldepth] {name} {dt} block-mode {mode}: loss rel {rel:.2e}, worst grad {worst[0]} {worst[1]:.2e}, grad rel-L2 {l2:.2e}")
     assert worst[1] <= gtol, (dt, mode, worst, l2)
     assert l2 <= l2tol, (dt, mode, l2, worst)
     return rel, worst, l2

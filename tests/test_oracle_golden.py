@@ -236,3 +236,24 @@ def test_mae_extractor(golden_dir, tag):
         tok = O.get_embeddings(P, cfg, x, use_tactile=(tag == "vt"))
         feat = O.transformer(tok, PL, "transformer.", 1, 4, 64).mean(1)
     np.testing.assert_allclose(feat.numpy(), z[tag + "/features"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [48, 192])
+def test_transformer_vs_reference_held_block(golden_dir, n):
+    """oracle.transformer (the vit-pytorch restatement every other fixture leans on) against the reference's OWN pre-norm block,
+    /root/reference/tactile_ssl/model/layers/block.py:89-114 + attention.py:54-76 + mlp.py:34-40 (tests/golden/block_stack.npz,
+    written by make_golden.run_block_stack from the imported reference classes): outputs, input gradient and every parameter gradient."""
+    z = _load(golden_dir, "block_stack")
+    D, depth, heads, mlp = [int(v) for v in z["meta"]]
+    P = {"t." + k[len("param/"):]: torch.tensor(z[k]).requires_grad_(True) for k in z.files if k.startswith("param/")}
+    assert P["t.layers.0.1.net.1.weight"].shape == (mlp, D)
+    x = torch.tensor(z[f"n{n}/x"]).requires_grad_(True)
+    first = O.transformer(x, P, "t.", 1, heads, D // heads, final_norm=False)
+    np.testing.assert_allclose(first.detach().numpy(), z[f"n{n}/block0_out"], rtol=1e-4, atol=1e-5)
+    y = O.transformer(x, P, "t.", depth, heads, D // heads)
+    np.testing.assert_allclose(y.detach().numpy(), z[f"n{n}/y"], rtol=1e-4, atol=1e-5)
+    (y * torch.tensor(z[f"n{n}/cot"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), z[f"n{n}/dx"], rtol=1e-3, atol=1e-5)
+    for k, p in P.items():
+        ref = z[f"n{n}/grad/" + k[2:]]
+        assert np.abs(p.grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6, k

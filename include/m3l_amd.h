@@ -55,6 +55,10 @@ int m3l_set_rowln(int enable);
  * attention backward block (correct, measured slower in the full step); env M3L_ATTN_BLOCK sets the initial mode.  Returns the
  * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
 int m3l_set_attn_block(int mode);
+/* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token
+ * rows per workgroup (t192.hip); on by default, env M3L_T192=0 or m3l_set_t192(0) falls back to the per-op kernels.  Returns the
+ * previous setting. */
+int m3l_set_t192(int on);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.

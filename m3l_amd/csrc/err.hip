@@ -1,0 +1,23 @@
+// Thread-local error string of the C ABI (include/m3l_amd.h: m3l_last_error); every launcher reports through m3l_set_error.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/m3l_amd.h"
+#include "common.cuh"
+
+static thread_local char g_err[512] = {0};
+void m3l_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int m3l_last_error(char* buf, size_t n) {
+    if (buf && n) {
+        strncpy(buf, g_err, n - 1);
+        buf[n - 1] = 0;
+    }
+    return (int)strlen(g_err);
+}

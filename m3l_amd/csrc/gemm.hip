@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -609,7 +611,6 @@ int m3l_gemm_init() {
     NT_ATTR5(bf16, 128); NT_ATTR5(float, 128); NT_ATTR5(bf16, 64); NT_ATTR5(float, 64);
 #undef NT_ATTR5
 #undef NT_ATTR
-    M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     g_gemm_inited = 1;
     return 0;
@@ -689,25 +690,30 @@ static int tn_splits(int M, int tiles) {
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out) {
     const int S = tn_splits(M, cdiv(N, 128) * cdiv(K, 128));
     if (splits_out) *splits_out = S;
-    return (size_t)S * N * K * sizeof(float);
+    TnProblem p;
+    memset(&p, 0, sizeof(p));
+    p.N = N; p.K = K;
+    return std::max((size_t)S * N * K * sizeof(float), m3l_wgrad_ws_bytes(M, &p, 1));
 }
 
+// workspace that serves either compute type (the f32 path launches chunks of <= 4 problems that reuse the same slabs)
 size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count) {
-    int tiles = 0;
-    size_t elems = 0;
-    for (int i = 0; i < count; ++i) {
-        tiles += cdiv(probs[i].N, 128) * cdiv(probs[i].K, 128);
-        elems += (size_t)probs[i].N * probs[i].K;
+    size_t f32 = 0;
+    for (int c0 = 0; c0 < count; c0 += 4) {
+        int tiles = 0;
+        size_t elems = 0;
+        for (int i = c0; i < std::min(count, c0 + 4); ++i) {
+            tiles += cdiv(probs[i].N, 128) * cdiv(probs[i].K, 128);
+            elems += (size_t)probs[i].N * probs[i].K;
+        }
+        f32 = std::max(f32, (size_t)tn_splits(M, tiles > 0 ? tiles : 1) * elems * sizeof(float));
     }
-    return (size_t)tn_splits(M, tiles > 0 ? tiles : 1) * elems * sizeof(float);
+    return std::max(f32, m3l_wgrad_ws_bytes(M, probs, count));
 }
 
-int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
-                        hipStream_t st, const float* extra_part, int extra_G, int extra_width, float* extra_out) {
-    if (m3l_gemm_init()) return 2;
-    M3L_CHECK(dtype == 0 || dtype == 1, "gemm_tn: bad dtype %d", dtype);
-    M3L_CHECK(count >= 1 && count <= 4 && M > 0, "gemm_tn_grouped: count=%d M=%d", count, M);
-    const int es = dtype ? 2 : 4;
+static int tn_grouped_f32(TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate, hipStream_t st,
+                          const float* extra_part, int extra_G, int extra_width, float* extra_out) {
+    const int dtype = 0;
     TnGroup grp;
     memset(&grp, 0, sizeof(grp));
     int tiles = 0, maxnk = 0;
@@ -717,14 +723,14 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
         TnProblem& p = probs[i];
         M3L_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0 && p.N % 8 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0,
                   "gemm_tn: N,K,ldy,ldx must be positive multiples of 8");
-        M3L_CHECK((long)M * p.ldy * es < 2147483647L && (long)M * p.ldx * es < 2147483647L, "gemm_tn: operand larger than 2 GiB");
+        M3L_CHECK((long)M * p.ldy * 4 < 2147483647L && (long)M * p.ldx * 4 < 2147483647L, "gemm_tn: operand larger than 2 GiB");
         p.tile0 = tiles;
         tiles += cdiv(p.N, 128) * cdiv(p.K, 128);
         if (p.N * p.K > maxnk) maxnk = p.N * p.K;
         flops += 2.0 * M * p.N * p.K;
-        bytes += (double)M * (p.N + p.K) * es;
+        bytes += (double)M * (p.N + p.K) * 4;
     }
-    const int unit = dtype ? 64 : 32;
+    const int unit = 32;
     int S = tn_splits(M, tiles);
     const int mps = cdiv(cdiv(M, S), unit) * unit;
     S = cdiv(M, mps);
@@ -744,15 +750,38 @@ int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* pa
     {
         ProfScope prof("gemm_tn", M, tiles, S, flops, st, bytes + (double)off * 4.0);
         dim3 g1(8 * tiles * cdiv(S, 8));
-        if (dtype == 1)
-            gemm_tn_glds_kernel<bf16><<<g1, 256, 65536, st>>>(grp, M, mps, S, partial_ws);
-        else
-            gemm_tn_glds_kernel<float><<<g1, 256, 65536, st>>>(grp, M, mps, S, partial_ws);
+        gemm_tn_glds_kernel<float><<<g1, 256, 65536, st>>>(grp, M, mps, S, partial_ws);
     }
     M3L_LAUNCH_CHECK();
     ProfScope prof2("gemm_tn_reduce", S, tiles, count, 0.0, st, (double)off * 4.0);
     reduce_splits_grouped_kernel<<<dim3(cdiv(maxnk, 256), count + (extra ? 1 : 0)), 256, 0, st>>>(grp, partial_ws, S, accumulate);
     M3L_LAUNCH_CHECK();
+    (void)dtype;
+    return 0;
+}
+
+int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
+                        hipStream_t st, const TnExtra* extras, int extra_count) {
+    if (m3l_gemm_init()) return 2;
+    M3L_CHECK(dtype == 0 || dtype == 1, "gemm_tn: bad dtype %d", dtype);
+    M3L_CHECK(count >= 1 && count <= M3L_TN_MAX_PROBLEMS && M > 0, "gemm_tn_grouped: count=%d M=%d", count, M);
+    if (dtype == 1) return m3l_wgrad_bf16(probs, count, M, partial_ws, ws_bytes, accumulate, st, extras, extra_count);
+    // f32: the 128 x 128 kernel takes 4 problems and one extra reduction per launch; chunks run back to back on the same slabs
+    int e = 0;
+    for (int c0 = 0; c0 < count; c0 += 4) {
+        const int n = std::min(4, count - c0);
+        const bool last = c0 + 4 >= count;
+        const TnExtra* x = e < extra_count ? &extras[e++] : nullptr;
+        if (tn_grouped_f32(probs + c0, n, M, partial_ws, ws_bytes, accumulate, st, x ? x->part : nullptr, x ? x->G : 0, x ? x->width : 0,
+                           x ? x->out : nullptr))
+            return 1;
+        if (last) {
+            while (e < extra_count) {                // more extras than chunks: plain row reductions
+                if (m3l_reduce_rows(extras[e].part, extras[e].G, extras[e].width, extras[e].width, extras[e].out, accumulate, st)) return 1;
+                ++e;
+            }
+        }
+    }
     return 0;
 }
 

@@ -110,10 +110,24 @@ struct TnGroup {
     float* extra_out;
     int extra_G, extra_width;
 };
+// bf16 problems take the 256 x 64 TBT kernel of wgrad.hip (up to M3L_TN_MAX_PROBLEMS per launch); f32 keeps the 128 x 128 kernel of
+// gemm.hip (launched in chunks of 4).  Extras: column reductions out[j] = sum_g part[g * width + j] carried by the reduce launch
+// (the fc1 bias gradients: per-row-block column sums written by the fused dgrad epilogues).
+#define M3L_TN_MAX_PROBLEMS 16
+#define M3L_TN_MAX_EXTRAS 4
+struct TnExtra {
+    const float* part;
+    float* out;
+    int G, width;
+};
 size_t m3l_gemm_tn_grouped_ws_bytes(int M, const TnProblem* probs, int count);
 int m3l_gemm_tn_grouped(int dtype, TnProblem* probs, int count, int M, float* partial_ws, size_t ws_bytes, int accumulate,
-                        hipStream_t st, const float* extra_part = nullptr, int extra_G = 0, int extra_width = 0,
-                        float* extra_out = nullptr);
+                        hipStream_t st, const TnExtra* extras = nullptr, int extra_count = 0);
+size_t m3l_wgrad_ws_bytes(int M, const TnProblem* probs, int count);
+// how many layers (each with the given `count` problems) one grouped launch should carry to give every CU a workgroup
+int m3l_wgrad_layers_per_launch(int M, const TnProblem* layer_probs, int count);
+int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_bytes, int accumulate, hipStream_t st, const TnExtra* extras,
+                   int extra_count);
 int m3l_gemm_init();
 int m3l_gemm_nt_colsum_rows(int M, int N);   // number of partial rows written through GemmEpi::colsum_part
 
@@ -135,6 +149,10 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
 int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres, const float* x, const float* ln1_w, const void* qkv,
                        const void* o, const float* lse, const void* woT, const void* wqkvT, float eps, void* dqkv, float* dx_out, void* dxt_out,
                        float* ln_part, hipStream_t st);
+// row-tiled fused half layers for long sequences (t192.hip): 192 token rows per workgroup, any M
+int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);
+int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
+                     void* u, void* h, float* xout, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

@@ -14,13 +14,6 @@
 #include "common.cuh"
 #include "kernels.h"
 
-static thread_local char g_err[512] = {0};
-void m3l_set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
 
 namespace {
 
@@ -163,17 +156,29 @@ struct TfLayer {
 struct TfWs {
     std::vector<TfLayer> L;
     float* dx;
-    void *dx_t[2], *dx1_t[2], *du[2], *dqkv[2];     // operands of the weight-gradient GEMMs: double-buffered by layer parity
-    void *dxn, *d_o;                                // (the wgrad of layer l runs on a side stream beside layer l-1's dgrads)
+    // operands of the weight-gradient GEMMs, a ring of `nset` per-layer sets (set of layer l = l % nset): the wgrads of `wg_batch`
+    // layers go out as ONE grouped launch on the side stream, beside the dgrad chains of the layers below
+    int nset, wg_batch;
+    std::vector<void*> dx_t, dx1_t, du, dqkv;
+    std::vector<float*> scratch2;   // [cdiv(M,128) or B][mlp] column-sum partials of the fused dgrad epilogue (fc1 bias gradient), per set
+    void *dxn, *d_o;
     float* scratch_tn;
     float* dsum;
     float* scratch;
-    float* scratch2[2];   // [cdiv(M,128)][mlp] column-sum partials of the fused dgrad epilogue (double-buffered like the wgrad operands)
     float* ln_part;       // [2 depth + 1][ln_part_stride]: dgamma / dbeta / bias-grad partials of every LayerNorm backward, reduced in one launch
     size_t ln_part_stride;
-    size_t scratch_b;
+    size_t scratch_b, scratch_tn_b;
     size_t total;
 };
+void layer_wgrad_problems(TnProblem* pr, int D, int HD, int mlp, bool project_out, int* np_out) {
+    memset(pr, 0, 4 * sizeof(TnProblem));
+    int np = 0;
+    pr[np].N = D; pr[np++].K = mlp;
+    pr[np].N = mlp; pr[np++].K = D;
+    pr[np].N = 3 * HD; pr[np++].K = D;
+    if (project_out) { pr[np].N = D; pr[np++].K = HD; }
+    *np_out = np;
+}
 TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     Arena a(ws);
     const size_t M = (size_t)B * n, D = c->dim, HD = (size_t)c->heads * 64, mlp = c->mlp_dim, e = esz(c->dtype);
@@ -195,7 +200,14 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
         l.xout = a.take_n<float>(M * D);
     }
     w.dx = a.take_n<float>(M * D);
-    for (int i = 0; i < 2; ++i) {
+    // layers per weight-gradient launch: enough tiles to give every CU a workgroup with >= ~2048 rows per split (wgrad.hip)
+    TnProblem pr[4 * 4];
+    int np = 0;
+    layer_wgrad_problems(pr, (int)D, (int)HD, (int)mlp, c->project_out != 0, &np);
+    w.wg_batch = c->dtype == 1 ? std::max(1, std::min(std::min(4, std::max(1, c->depth)), m3l_wgrad_layers_per_launch((int)M, pr, np))) : 1;
+    w.nset = std::max(1, std::min(std::max(1, c->depth), 2 * w.wg_batch));
+    w.dx_t.resize(w.nset); w.dx1_t.resize(w.nset); w.du.resize(w.nset); w.dqkv.resize(w.nset); w.scratch2.resize(w.nset);
+    for (int i = 0; i < w.nset; ++i) {
         w.dx_t[i] = a.take(M * D * e);
         w.dx1_t[i] = a.take(M * D * e);
         w.du[i] = a.take(M * mlp * e);
@@ -206,16 +218,11 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.dsum = a.take_n<float>((size_t)B * c->heads * n);
     std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
     w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
-    {
-        TnProblem pr[4];
-        memset(pr, 0, sizeof(pr));
-        pr[0].N = (int)D; pr[0].K = (int)mlp; pr[1].N = (int)mlp; pr[1].K = (int)D;
-        pr[2].N = (int)(3 * HD); pr[2].K = (int)D; pr[3].N = (int)D; pr[3].K = (int)HD;
-        w.scratch_b = std::max(w.scratch_b, m3l_gemm_tn_grouped_ws_bytes((int)M, pr, 4));
-    }
+    for (int j = 1; j < w.wg_batch; ++j) memcpy(pr + j * np, pr, np * sizeof(TnProblem));
+    w.scratch_tn_b = m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * w.wg_batch);
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
-    w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_b));
-    for (int i = 0; i < 2; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B) * mlp);   // B: one partial row per sample (block kernels)
+    w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_tn_b));
+    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B) * mlp);   // B: one partial row per sample (block kernels)
     w.ln_part_stride = (size_t)std::max(m3l_ln_bwd_blocks((int)M), B) * 3 * D;
     w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
@@ -243,14 +250,6 @@ int m3l_set_rowln(int enable) {
     const int old = use_rowln() ? 1 : 0;
     g_rowln = enable ? 1 : 0;
     return old;
-}
-
-int m3l_last_error(char* buf, size_t n) {
-    if (buf && n) {
-        strncpy(buf, g_err, n - 1);
-        buf[n - 1] = 0;
-    }
-    return (int)strlen(g_err);
 }
 
 int m3l_mask_counts(const m3l_geom* g, double ratio, int* counts_host) {
@@ -496,6 +495,12 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             x = L.xout;
             continue;
         }
+        if (!block && !fuse && m3l_mlp_t192_supported(dt, D, mlp, M)) {
+            // long sequences: fc1 + GELU + fc2 + residual per 192-row tile, the hidden activation never leaves the CU between the GEMMs
+            if (m3l_mlp_t192_fwd(M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
+            x = L.xout;
+            continue;
+        }
         e = epi0(mlp);
         e.bias = fc1_b; e.act = 1; e.out_pre = L.u; e.out_t = L.h;
         if (m3l_gemm_nt(dt, L.xn2, D, L.w1, D, M, mlp, D, &e, st)) return 1;
@@ -565,9 +570,10 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     float* const* gf = grads + 11 * c->depth;
     // every ln_bwd also emits its result in the compute type (operand of the next GEMMs) and the column sums of it
     // (= bias gradient of the Linear that produced the residual branch): no separate cast / colsum passes.
+    const int NS = w.nset;
     if (layer_hi == c->depth) {
         float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;   // fc2 bias of the last layer
-        const int top = (c->depth - 1) & 1;
+        const int top = c->depth ? (c->depth - 1) % NS : 0;
         if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt,
                        ln_slot(2 * c->depth, gf[0], gf[1], db_last), nullptr, nullptr, nullptr, 0, st))
             return 1;
@@ -575,16 +581,41 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     if (side_init()) return 2;
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, mlp) && m3l_gemm_nt_rowln_supported(dt, D, 3 * HD);
     hipStream_t s2 = g_side.s;
-    hipEvent_t wg_done[2] = {nullptr, nullptr};       // completion of the wgrad that last read buffer set i
+    std::vector<hipEvent_t> set_done(NS, nullptr);    // completion of the wgrad launch that last read operand set i
+    std::vector<hipEvent_t> launched;                 // every wgrad launch of this call (joined at the end)
+    std::vector<TnProblem> pend;                      // weight-gradient problems of the layers waiting for the next grouped launch
+    std::vector<TnExtra> pend_ex;
+    std::vector<int> pend_sets;
+    auto flush_wgrads = [&]() -> int {
+        if (pend.empty()) return 0;
+        hipEvent_t ready = side_event();
+        M3L_HIP(hipEventRecord(ready, st));
+        M3L_HIP(hipStreamWaitEvent(s2, ready, 0));
+        if (m3l_gemm_tn_grouped(dt, pend.data(), (int)pend.size(), M, w.scratch_tn, w.scratch_tn_b, 0, s2, pend_ex.data(), (int)pend_ex.size()))
+            return 1;
+        hipEvent_t done = side_event();
+        M3L_HIP(hipEventRecord(done, s2));
+        for (int sidx : pend_sets) set_done[sidx] = done;
+        launched.push_back(done);
+        pend.clear(); pend_ex.clear(); pend_sets.clear();
+        return 0;
+    };
+    // before a kernel overwrites operand set i: the weight-gradient launch that read its previous contents must be done
+    auto claim_set = [&](int i) -> int {
+        if (set_done[i]) {
+            M3L_HIP(hipStreamWaitEvent(st, set_done[i], 0));
+            set_done[i] = nullptr;
+        }
+        return 0;
+    };
     const int csrows = m3l_gemm_nt_colsum_rows(M, mlp);
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         TfLayer& L = w.L[l];
-        const int cur = l & 1;
+        const int cur = l % NS, nxt = l ? (l - 1) % NS : 0;
         const float* xl = l ? w.L[l - 1].xout : x_in;
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
-        // buffer set `cur` was last read by the side-stream wgrad of layer l+2: it must have finished before we overwrite it
-        // (dx_t[cur] was already written by layer l+1's last kernel, which waited on the same event — see below)
+        // set `cur` (dx_t[cur] was written by layer l+1's last kernel, which claimed the set) receives du / dx1_t / dqkv of this layer
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
         GemmEpi e = epi0(mlp);
         const bool mlp_block = !fuse && m3l_mlp_block_bwd_supported(dt, D, mlp, n);
@@ -622,11 +653,11 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         float* dx_dst = (l == 0 && dx_in) ? dx_in : w.dx;
         float* db_prev = l ? grads[11 * (l - 1) + 10] : nullptr;                                      // fc2 bias of layer l-1
         if (attn_block) {
-            // short sequences: dO, the attention backward, dxn1 and the LN1 backward in one launch.  It writes dx_t[cur^1] (the next
-            // layer's operand set), which the side-stream wgrad of layer l+1 may still be reading.
-            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
+            // short sequences: dO, the attention backward, dxn1 and the LN1 backward in one launch.  It writes dx_t[nxt] (the next
+            // layer's operand set)
+            if (l && claim_set(nxt)) return 2;
             if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
-                                   dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+                                   dx_dst, l ? w.dx_t[nxt] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                 return 1;
         }
         const void* d_o = w.dx1_t[cur];
@@ -639,31 +670,26 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         if (m3l_attn_bwd(dt, L.qkv, L.o, d_o, L.lse, w.dsum, w.dqkv[cur], B, n, c->heads, st)) return 1;
         }
-        // ---- all weight gradients of the layer: ONE grouped TN launch + one reduce, on the side stream, overlapping the
-        // rest of this layer's and the next layer's dgrad chain (these kernels alone do not fill 256 CUs at M = B*48)
+        // ---- the weight gradients of the layer join the pending group; every wg_batch layers (and at the end of the range) the group
+        // goes out as ONE grouped TN launch + one reduce on the side stream, overlapping the dgrad chains of the layers below
         {
-            hipEvent_t ready = side_event();
-            M3L_HIP(hipEventRecord(ready, st));
-            M3L_HIP(hipStreamWaitEvent(s2, ready, 0));
-            TnProblem pr[4];
-            memset(pr, 0, sizeof(pr));
-            int np = 0;
-            pr[np++] = TnProblem{w.dx_t[cur], L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0};           // dW2 = dx^T h
-            pr[np++] = TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0};             // dW1 = du^T xn2
-            pr[np++] = TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}; // dWqkv = dqkv^T xn1
-            if (c->project_out) pr[np++] = TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0};   // dWo = dx1^T o
-            if (m3l_gemm_tn_grouped(dt, pr, np, M, w.scratch_tn, w.scratch_b, 0, s2, w.scratch2[cur], cs_rows, mlp, g[8])) return 1;
-            wg_done[cur] = side_event();
-            M3L_HIP(hipEventRecord(wg_done[cur], s2));
+            pend.push_back(TnProblem{w.dx_t[cur], L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0});           // dW2 = dx^T h
+            pend.push_back(TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0});             // dW1 = du^T xn2
+            pend.push_back(TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}); // dWqkv = dqkv^T xn1
+            if (c->project_out) pend.push_back(TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0});   // dWo = dx1^T o
+            pend_ex.push_back(TnExtra{w.scratch2[cur], g[8], cs_rows, mlp});                                // fc1 bias gradient
+            pend_sets.push_back(cur);
+            if ((int)pend_sets.size() >= w.wg_batch || l == layer_lo) {
+                if (int rc = flush_wgrads()) return rc;
+            }
         }
-        // the last kernel of this layer writes dx_t[cur^1] (and the next layer then du/dx1_t/dqkv[cur^1]): the wgrad of layer
-        // l+1, which reads that set, must be done
+        // the last kernel of this layer writes dx_t[nxt] (and the next layer then du / dx1_t / dqkv[nxt])
         if (attn_block) continue;
         if (fuse) {
-            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
+            if (l && claim_set(nxt)) return 2;
             RowLnEpi r;
             memset(&r, 0, sizeof(r));
-            r.x = xl; r.gamma = (const float*)t[0]; r.res = w.dx; r.x_out = dx_dst; r.out_t = l ? w.dx_t[cur ^ 1] : nullptr;
+            r.x = xl; r.gamma = (const float*)t[0]; r.res = w.dx; r.x_out = dx_dst; r.out_t = l ? w.dx_t[nxt] : nullptr;
             r.part = w.scratch; r.eps = LN_EPS;
             if (m3l_gemm_nt_rowln(dt, ROWLN_BWD, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &r, st)) return 1;   // dxn1 + LN1 backward
             if (m3l_reduce_rows_seg3(w.scratch, cdiv(M, 64), D, g[0], g[1], db_prev, 0, st)) return 1;
@@ -671,8 +697,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             e = epi0(D);
             e.out_t = w.dxn;
             if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
-            if (wg_done[cur ^ 1]) M3L_HIP(hipStreamWaitEvent(st, wg_done[cur ^ 1], 0));
-            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[cur ^ 1] : nullptr, dt,
+            if (l && claim_set(nxt)) return 2;
+            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[nxt] : nullptr, dt,
                            ln_slot(2 * l, g[0], g[1], db_prev), nullptr, nullptr, nullptr, 0, st))
                 return 1;
         }
@@ -689,8 +715,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         M3L_HIP(hipStreamWaitEvent(st, red_done, 0));     // also orders every earlier side-stream kernel (the weight gradients)
     }
     // join: every weight gradient is complete before anything later on the caller's stream
-    for (int i = 0; i < 2; ++i)
-        if (wg_done[i]) M3L_HIP(hipStreamWaitEvent(st, wg_done[i], 0));
+    for (hipEvent_t ev : launched) M3L_HIP(hipStreamWaitEvent(st, ev, 0));
     if (c->depth == 0 && dx_in && layer_hi == 0) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }

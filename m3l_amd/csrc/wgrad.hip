@@ -1,0 +1,336 @@
+// Weight gradients dW[N, K] = Y^T X (sum over the M token rows) for bf16 operands on gfx950 — every nn.Linear.weight.grad of the
+// MAE step (reference: autograd through vit_pytorch Attention.to_qkv / to_out, FeedForward.net[1] / net[4] and the patch / head
+// Linears, models/pretrain_models.py:111,115,116,770,777 via loss.backward(), models/ppo_mae.py:263).
+//
+// Grouped: up to 16 problems that share M (the four weights of up to four transformer layers) in ONE launch + one reduce.
+//   tile      256 (the wider of N / K) x 64 TBT (the narrower; TBT = 2, 3, 4 picked per launch), 8 waves, wave tile 64 x 32 TBT
+//             -> 110 MAC per staged element at 256 x 192 (the 128 x 128 tile of round 1: 64), so the L2 -> LDS stream no longer
+//             bounds the MFMA rate;
+//   staging   both operands by bounds-checked LDS-DMA (buffer_load ... lds, rows >= M read as zero) issued from INLINE ASM: the
+//             compiler does not see the LDS write, so it does not drain vmcnt(0) in front of the next ds_read (it does for the
+//             builtin form: round 1's kernel waited for every prefetch before computing).  Two 64-row stages; the wave waits for
+//             its own pieces with s_waitcnt vmcnt(0) at the TOP of the next step, i.e. a whole MFMA block after issuing them;
+//   LDS image 64-column panels of [64 rows][128 B]; 16-byte chunk index XOR 2 ((row >> 1) & 3), applied on the per-lane SOURCE
+//             address (the DMA destination is lane-linear) and on the read: the 8 rows a half-wave's ds_read_b64_tr_b16 touches
+//             fall on 8 distinct 32-byte bank slots (conflict-free k-strided transpose reads);
+//   split-M   S = #CU / tiles row ranges (>= 1 workgroup per CU, <= 1 round), each writing its fp32 tile in FRAGMENT order (one
+//             1-KiB contiguous store per accumulator tile); the reduce kernel sums the S slabs in fixed order (deterministic,
+//             float4 coalesced reads) and scatters to dW with the problem's strides and valid ranges.
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int WG_THREADS = 512;
+constexpr int WG_TA = 256;
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+struct WgProb {
+    const bf16* A;      // wide operand   [M][lda], a columns
+    const bf16* B;      // narrow operand [M][ldb], b columns
+    float* out;         // out[ia * so_a + ib * so_b]
+    int lda, ldb, a, b, so_a, so_b, avalid, bvalid;
+    int tile0, tiles_b;
+};
+struct WgExtra {
+    const float* part;  // [G][width] partial rows
+    float* out;         // [width]
+    int G, width;
+};
+struct WgGroup {
+    WgProb p[M3L_TN_MAX_PROBLEMS];
+    WgExtra ex[M3L_TN_MAX_EXTRAS];
+    int count, tiles_total, extra_count;
+};
+
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 B, lane-linear at lds_dst) through a buffer resource; M0 carries the LDS base and is
+// restored (the compiler reserves it).  Not counted by the compiler: pair with an explicit s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void dma16(int4v rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ int4v make_rsrc(const void* p, long bytes) {
+    const unsigned long a = (unsigned long)p;
+    int4v r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 2147483647L ? 2147483647L : bytes));
+    r[3] = __builtin_amdgcn_readfirstlane(0x00020000);
+    return r;
+}
+
+// fragment of a [64 k-rows][64 cols] panel (128-byte rows, swizzled): lane (i, g) <- element j = panel[(k0 + kacc(g, j))][c0 + i]
+__device__ __forceinline__ Frag<bf16> ldtr(const char* panel, int k0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = k0 + 4 * g + q;
+    const int chunk = (c0 >> 3) + (p >> 1);
+    const int x = ((chunk ^ (2 * ((r0 >> 1) & 3))) << 4) + (p & 1) * 8;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(panel + r0 * 128 + x));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(panel + (r0 + 16) * 128 + x));
+    Frag<bf16> f;
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+    return f;
+}
+
+template <int TBT>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs) {
+    constexpr int TB = 64 * TBT, NP = 4 + TBT, STAGE = NP * 8192, NB = TB / 32, NT = 4 * NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware order: the tiles of one row range read the same rows of their operands -> ids that differ by multiples of 8
+    const int bid = blockIdx.x, rest = bid >> 3;
+    const int gtile = rest % grp.tiles_total, sp = (rest / grp.tiles_total) * 8 + (bid & 7);
+    if (sp >= nsplit) return;
+    int pi = 0;
+    for (int i = 1; i < grp.count; ++i)
+        if (gtile >= grp.p[i].tile0) pi = i;
+    const WgProb& pb = grp.p[pi];
+    const int tile = gtile - pb.tile0;
+    const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
+    const int m_beg = sp * rows_per_split;
+    const int m_end = min(M, m_beg + rows_per_split);
+    const int nsteps = (m_end - m_beg + 63) >> 6;
+
+    const int4v rsA = make_rsrc(pb.A, (long)M * pb.lda * 2), rsB = make_rsrc(pb.B, (long)M * pb.ldb * 2);
+    // this wave's NP pieces of a stage: piece q = wave * NP + j = (panel q >> 3, row group q & 7); panels 0..3 = A, 4.. = B
+    unsigned voff[NP], vinc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = wave * NP + j, panel = q >> 3, rg = q & 7;
+        const int row = rg * 8 + (lane >> 3);
+        const int csrc = (lane & 7) ^ (2 * ((row >> 1) & 3));
+        const bool isa = panel < 4;
+        const int ld = isa ? pb.lda : pb.ldb;
+        int col = isa ? (a0 + 64 * panel + csrc * 8) : (b0 + 64 * (panel - 4) + csrc * 8);
+        col = min(col, (isa ? pb.a : pb.b) - 8);              // columns past the operand: any valid chunk (never stored)
+        voff[j] = (unsigned)(((long)(m_beg + row) * ld + col) * 2);
+        vinc[j] = (unsigned)(64 * ld * 2);
+    }
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int st, int t) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = wave * NP + j;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + q * 1024);
+            if ((q >> 3) < 4) dma16(rsA, voff[j] + (unsigned)t * vinc[j], dst);
+            else dma16(rsB, voff[j] + (unsigned)t * vinc[j], dst);
+        }
+    };
+
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < NB; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nsteps > 0) issue(0, 0);
+    for (int t = 0; t < nsteps; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t (issued one MFMA block ago) have landed
+        __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done reading the other stage
+        asm volatile("" ::: "memory");
+        if (t + 1 < nsteps) issue(cur ^ 1, t + 1);
+        const char* As = smem + cur * STAGE + wr * 8192;
+        const char* Bs = smem + cur * STAGE + 4 * 8192;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<bf16> fa[4], fb[NB];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) fa[x] = ldtr(As, ks * 32, x * 16, lane);
+#pragma unroll
+            for (int y = 0; y < NB; ++y) {
+                const int col = wc * (TB / 2) + y * 16;
+                fb[y] = ldtr(Bs + (col >> 6) * 8192, ks * 32, col & 63, lane);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y) acc[x][y] = mma16(fa[x], fb[y], acc[x][y]);
+        }
+    }
+    // fragment-order slab: [wave][tile x * NB + y][lane] float4 (rows 4 g .. 4 g + 3 of the 16 x 16 tile, column li)
+    float* S = slabs + ((long)sp * grp.tiles_total + gtile) * (long)(WG_TA * TB);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < NB; ++y)
+            *reinterpret_cast<f32x4*>(S + (((wave * NT + x * NB + y) * 64 + lane) << 2)) = acc[x][y];
+}
+
+template <int TBT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const float* __restrict__ slabs, int S, int accumulate) {
+    constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int gt = blockIdx.y;
+    if (gt >= grp.tiles_total) {                     // extra column reductions (bias-gradient partial rows)
+        const WgExtra& e = grp.ex[gt - grp.tiles_total];
+        if (f >= e.width) return;
+        float s0 = 0.f, s1 = 0.f;
+        int g = 0;
+        for (; g + 1 < e.G; g += 2) {
+            s0 += e.part[(long)g * e.width + f];
+            s1 += e.part[(long)(g + 1) * e.width + f];
+        }
+        if (g < e.G) s0 += e.part[(long)g * e.width + f];
+        e.out[f] = accumulate ? e.out[f] + (s0 + s1) : (s0 + s1);
+        return;
+    }
+    if (f >= 64 * TB) return;
+    int pi = 0;
+    for (int i = 1; i < grp.count; ++i)
+        if (gt >= grp.p[i].tile0) pi = i;
+    const WgProb& pb = grp.p[pi];
+    const int tile = gt - pb.tile0;
+    const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
+    const long stride = (long)grp.tiles_total * (WG_TA * TB);
+    const float* P = slabs + (long)gt * (WG_TA * TB) + ((long)f << 2);
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int i = 0;
+    for (; i + 1 < S; i += 2) {
+        s0 += *reinterpret_cast<const f32x4*>(P + (long)i * stride);
+        s1 += *reinterpret_cast<const f32x4*>(P + (long)(i + 1) * stride);
+    }
+    if (i < S) s0 += *reinterpret_cast<const f32x4*>(P + (long)i * stride);
+    s0 += s1;
+    const int lane = f & 63, wt = f >> 6, t = wt % NT, w = wt / NT, x = t / NB, y = t % NB;
+    const int ia = a0 + (w >> 1) * 64 + x * 16 + 4 * (lane >> 4);
+    const int ib = b0 + (w & 1) * (TB / 2) + y * 16 + (lane & 15);
+    if (ib >= pb.bvalid) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (ia + r >= pb.avalid) break;
+        float* o = pb.out + (long)(ia + r) * pb.so_a + (long)ib * pb.so_b;
+        *o = accumulate ? (*o + s0[r]) : s0[r];
+    }
+}
+
+int g_ncu = 0;
+int cu_count() {
+    if (!g_ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_ncu = n;
+    }
+    return g_ncu;
+}
+
+struct WgPlanHost {
+    int tbt, tiles_total, S, rows_per_split;
+    size_t ws_bytes;
+};
+// wide / narrow orientation and tiling of a problem list (the same decisions for the size query and the launch)
+WgPlanHost plan_of(int M, const TnProblem* probs, int count, WgGroup* grp) {
+    WgPlanHost pl;
+    long best = -1;
+    pl.tbt = 3;
+    for (int tbt = 2; tbt <= 4; ++tbt) {
+        long cost = 0;
+        for (int i = 0; i < count; ++i) {
+            const int a = std::max(probs[i].N, probs[i].K), b = std::min(probs[i].N, probs[i].K);
+            cost += (long)cdiv(a, WG_TA) * cdiv(b, 64 * tbt) * tbt;
+        }
+        if (best < 0 || cost <= best) {      // ties: the wider tile (more MACs per staged byte)
+            best = cost;
+            pl.tbt = tbt;
+        }
+    }
+    const int TB = 64 * pl.tbt;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const TnProblem& p = probs[i];
+        const bool y_wide = p.N >= p.K;
+        const int a = y_wide ? p.N : p.K, b = y_wide ? p.K : p.N;
+        const int tb = cdiv(b, TB);
+        if (grp) {
+            WgProb& w = grp->p[i];
+            w.A = (const bf16*)(y_wide ? p.Y : p.X); w.B = (const bf16*)(y_wide ? p.X : p.Y);
+            w.lda = y_wide ? p.ldy : p.ldx; w.ldb = y_wide ? p.ldx : p.ldy;
+            w.a = a; w.b = b;
+            w.out = p.out;
+            w.so_a = y_wide ? p.ldo : 1; w.so_b = y_wide ? 1 : p.ldo;
+            w.avalid = y_wide ? p.nvalid : p.kvalid; w.bvalid = y_wide ? p.kvalid : p.nvalid;
+            w.tile0 = tiles; w.tiles_b = tb;
+        }
+        tiles += cdiv(a, WG_TA) * tb;
+    }
+    pl.tiles_total = tiles;
+    int S = std::max(1, cu_count() / std::max(1, tiles));
+    S = std::min(S, std::max(1, M / 256));                     // at least 256 rows per split
+    pl.rows_per_split = cdiv(cdiv(M, S), 64) * 64;
+    pl.S = cdiv(M, pl.rows_per_split);
+    pl.ws_bytes = (size_t)pl.S * tiles * WG_TA * TB * sizeof(float);
+    return pl;
+}
+
+}  // namespace
+
+size_t m3l_wgrad_ws_bytes(int M, const TnProblem* probs, int count) { return plan_of(M, probs, count, nullptr).ws_bytes; }
+
+int m3l_wgrad_layers_per_launch(int M, const TnProblem* layer_probs, int count) {
+    const int tiles = plan_of(M, layer_probs, count, nullptr).tiles_total;
+    const long wgs = (long)tiles * std::max(1, M / 2048);      // workgroups of one layer at >= 2048 rows per split
+    return (int)std::max(1L, std::min(4L, (cu_count() + wgs - 1) / wgs));
+}
+
+int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_bytes, int accumulate, hipStream_t st, const TnExtra* extras,
+                   int extra_count) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 6 * 8192));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 8192));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8192));
+        inited = 1;
+    }
+    M3L_CHECK(count >= 1 && count <= M3L_TN_MAX_PROBLEMS && M > 0, "wgrad: count=%d M=%d", count, M);
+    M3L_CHECK(extra_count >= 0 && extra_count <= M3L_TN_MAX_EXTRAS, "wgrad: %d extra reductions", extra_count);
+    WgGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        const TnProblem& p = probs[i];
+        M3L_CHECK(p.N >= 8 && p.K >= 8 && p.K % 8 == 0 && p.N % 8 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0,
+                  "wgrad: N, K, ldy, ldx must be positive multiples of 8 (N=%d K=%d ldy=%d ldx=%d)", p.N, p.K, p.ldy, p.ldx);
+        M3L_CHECK((long)M * p.ldy * 2 < 2147483647L && (long)M * p.ldx * 2 < 2147483647L, "wgrad: operand larger than 2 GiB");
+        flops += 2.0 * M * p.N * p.K;
+        bytes += 2.0 * M * (p.N + p.K);
+    }
+    const WgPlanHost pl = plan_of(M, probs, count, &grp);
+    grp.count = count;
+    grp.tiles_total = pl.tiles_total;
+    grp.extra_count = extra_count;
+    int maxw = 0;
+    for (int i = 0; i < extra_count; ++i) {
+        grp.ex[i] = WgExtra{extras[i].part, extras[i].out, extras[i].G, extras[i].width};
+        maxw = std::max(maxw, extras[i].width);
+    }
+    M3L_CHECK(ws_bytes >= pl.ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
+    const int TB = 64 * pl.tbt;
+    {
+        ProfScope prof("wgrad", M, pl.tiles_total, pl.S, flops, st, bytes + (double)pl.ws_bytes);
+        const dim3 g1(8 * pl.tiles_total * cdiv(pl.S, 8));
+        const size_t lds = (size_t)2 * (4 + pl.tbt) * 8192;
+        if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
+        else if (pl.tbt == 3) wgrad_kernel<3><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
+        else wgrad_kernel<4><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
+    }
+    M3L_LAUNCH_CHECK();
+    ProfScope prof2("wgrad_reduce", pl.S, pl.tiles_total, count, 0.0, st, (double)pl.ws_bytes);
+    const dim3 g2(cdiv(std::max(64 * TB, maxw), 256), pl.tiles_total + extra_count);
+    if (pl.tbt == 2) wgrad_reduce_kernel<2><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
+    else if (pl.tbt == 3) wgrad_reduce_kernel<3><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
+    else wgrad_reduce_kernel<4><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}

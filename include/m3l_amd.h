@@ -50,14 +50,15 @@ int m3l_version(void);
 int m3l_last_error(char* buf, size_t n);
 /* experimental: run the LayerNorms inside the epilogue of the neighbouring GEMM (returns the previous setting; default off) */
 int m3l_set_rowln(int enable);
-/* fused per-sample block kernels for short sequences (bf16, dim 128 / 192, heads = dim / 64, n <= 48): mode 0 = off, 1 (default) =
- * forward attention block (LN1 + QKV + attention + out-proj + residual + LN2) + forward / backward MLP blocks, 3 = also the
- * attention backward block (correct, measured slower in the full step); env M3L_ATTN_BLOCK sets the initial mode.  Returns the
+/* fused per-sample block kernels for short sequences (bf16, dim 128 / 192, heads = dim / 64, n <= 48): mode 0 = off, 1 =
+ * forward attention block (LN1 + QKV + attention + out-proj + residual + LN2) + forward / backward MLP blocks, 3 (default) = also
+ * the attention backward block; env M3L_ATTN_BLOCK sets the initial mode.  Returns the
  * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
 int m3l_set_attn_block(int mode);
 /* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token
- * rows per workgroup (t192.hip); on by default, env M3L_T192=0 or m3l_set_t192(0) falls back to the per-op kernels.  Returns the
- * previous setting. */
+ * rows per workgroup (t192.hip).  Bit mask: 1 (default) = sequences longer than 48 tokens, 2 = also the MLP halves of short
+ * sequences (48-row tiles, two chunk parities; correct, measured equal to the per-sample block kernels); env M3L_T192 sets the
+ * initial mode, 0 falls back to the per-op kernels.  Returns the previous mode. */
 int m3l_set_t192(int on);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
 static int ab_state() {
     if (!g_ab_state) {
         const char* e = getenv("M3L_ATTN_BLOCK");
-        g_ab_state = e ? (atoi(e) > 0 ? atoi(e) : -1) : 1;
+        g_ab_state = e ? (atoi(e) > 0 ? atoi(e) : -1) : 3;
     }
     return g_ab_state;
 }
@@ -784,10 +784,9 @@ int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out
     return dtype == 1 && project_out && (D == 128 || D == 192) && heads * 64 == D && n >= 1 && n <= 48;
 }
 
-// The attention BACKWARD block is correct (tests run it) but off by default: with one 149 KB workgroup per CU it cannot share a CU
-// with the 64 KB weight-gradient workgroups of the side stream, and once both halves of the backward are fused the per-layer
-// compute-stream time (56 us) drops below the side stream's (65 us) so the weight gradients stop being hidden: 47.8k -> 42.8k
-// samples/s at cfg 2.  M3L_ATTN_BLOCK=3 (or m3l_set_attn_block(3)) enables it.
+// The attention BACKWARD block (mode bit 2).  Round 1 kept it opt-in: the weight-gradient side stream (2.5 ms per step) then bounded
+// the encoder backward and fusing more of the compute stream only exposed it (47.8k -> 42.8k samples/s).  With the round-2 weight
+// gradient kernel (wgrad.hip, 1.1 ms per step) it pays: 49.4k -> 50.7k, so mode 3 is the default.
 int m3l_attn_block_bwd_enabled(void) { return ab_state() > 0 && (g_ab_state & 2); }
 
 int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, const float* ln1_b, const void* wqkv, const void* wo,

@@ -222,8 +222,8 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.scratch_tn_b = m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * w.wg_batch);
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_tn_b));
-    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B) * mlp);   // B: one partial row per sample (block kernels)
-    w.ln_part_stride = (size_t)std::max(m3l_ln_bwd_blocks((int)M), B) * 3 * D;
+    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B), m3l_mlp_t192_tiles((int)M)) * mlp);   // B: one partial row per sample (block kernels)
+    w.ln_part_stride = (size_t)std::max(std::max(m3l_ln_bwd_blocks((int)M), B), m3l_mlp_t192_tiles((int)M)) * 3 * D;
     w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
     return w;
@@ -489,13 +489,13 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             if (m3l_ln_fwd(dt, L.x1, M, D, ln2_w, ln2_b, LN_EPS, L.xn2, nullptr, st)) return 1;
         }
         }
-        if (block && m3l_mlp_block_supported(dt, D, mlp, n)) {
+        if (block && !(m3l_mlp_t192_short() && m3l_mlp_t192_supported(dt, D, mlp, M)) && m3l_mlp_block_supported(dt, D, mlp, n)) {
             // the feed-forward half in one launch as well
             if (m3l_mlp_block_fwd(D, mlp, B, n, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
             x = L.xout;
             continue;
         }
-        if (!block && !fuse && m3l_mlp_t192_supported(dt, D, mlp, M)) {
+        if (!fuse && m3l_mlp_t192_supported(dt, D, mlp, M)) {
             // long sequences: fc1 + GELU + fc2 + residual per 192-row tile, the hidden activation never leaves the CU between the GEMMs
             if (m3l_mlp_t192_fwd(M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
             x = L.xout;
@@ -580,7 +580,9 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     }
     if (side_init()) return 2;
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, mlp) && m3l_gemm_nt_rowln_supported(dt, D, 3 * HD);
-    hipStream_t s2 = g_side.s;
+    // M3L_WGRAD_INLINE=1: weight gradients on the caller's stream (no overlap, no HBM contention with the dgrad chain) — diagnostic
+    static const bool wg_inline = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0;
+    hipStream_t s2 = wg_inline ? st : g_side.s;
     std::vector<hipEvent_t> set_done(NS, nullptr);    // completion of the wgrad launch that last read operand set i
     std::vector<hipEvent_t> launched;                 // every wgrad launch of this call (joined at the end)
     std::vector<TnProblem> pend;                      // weight-gradient problems of the layers waiting for the next grouped launch
@@ -588,6 +590,12 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     std::vector<int> pend_sets;
     auto flush_wgrads = [&]() -> int {
         if (pend.empty()) return 0;
+        if (wg_inline) {
+            if (m3l_gemm_tn_grouped(dt, pend.data(), (int)pend.size(), M, w.scratch_tn, w.scratch_tn_b, 0, st, pend_ex.data(), (int)pend_ex.size()))
+                return 1;
+            pend.clear(); pend_ex.clear(); pend_sets.clear();
+            return 0;
+        }
         hipEvent_t ready = side_event();
         M3L_HIP(hipEventRecord(ready, st));
         M3L_HIP(hipStreamWaitEvent(s2, ready, 0));
@@ -618,7 +626,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         // set `cur` (dx_t[cur] was written by layer l+1's last kernel, which claimed the set) receives du / dx1_t / dqkv of this layer
         // ---- feed-forward: x_out = x1 + fc2(gelu(fc1(LN2(x1))))
         GemmEpi e = epi0(mlp);
-        const bool mlp_block = !fuse && m3l_mlp_block_bwd_supported(dt, D, mlp, n);
+        const bool mlp_t192 = !fuse && m3l_mlp_t192_supported(dt, D, mlp, M) && (m3l_mlp_t192_short() || !m3l_mlp_block_bwd_supported(dt, D, mlp, n));
+        const bool mlp_block = !fuse && !mlp_t192 && m3l_mlp_block_bwd_supported(dt, D, mlp, n);
         int cs_rows = csrows;
         if (mlp_block) {
             // short sequences: du, its column sums, dxn2 and the LN2 backward in one launch; one partial row per sample
@@ -626,12 +635,18 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             if (m3l_mlp_block_bwd(D, mlp, B, n, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
                                   w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, B), st))
                 return 1;
+        } else if (mlp_t192) {
+            // long sequences: the same chain per 192-row tile; one partial row per tile
+            cs_rows = m3l_mlp_t192_tiles(M);
+            if (m3l_mlp_t192_bwd(M, mlp, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
+                                 w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, cs_rows), st))
+                return 1;
         } else {
         e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2[cur];
         if (m3l_gemm_nt(dt, w.dx_t[cur], D, L.w2T, D, M, mlp, D, &e, st)) return 1;                   // du = (dx W2) * gelu'(u)
         // (the per-row-block column sums in scratch2[cur] = fc1 bias gradient partials are reduced by the wgrad group's reduce)
         }
-        if (mlp_block) {
+        if (mlp_block || mlp_t192) {
         } else if (fuse) {
             // dxn2 = du W1 and the LN2 backward in one kernel: dx1 = dx + dLN(dxn2) (in place) + compute-type copy + partials
             RowLnEpi r;

@@ -26,12 +26,25 @@
 namespace {
 
 constexpr int T_D = 192;
-constexpr int T_TOK = 192;
-constexpr int T_CW = 12, T_DW = 4;
-constexpr int T_THREADS = 64 * (T_CW + T_DW);
+constexpr int T_DW = 4;                      // DMA-only waves
 constexpr int T_BLK = 12288;                 // one weight block
-constexpr int T_STAGE = 2 * T_BLK;           // a ring stage = the two blocks of one 32-wide chunk
-constexpr int T_NSTAGE = 4;
+constexpr int T_CHUNK = 2 * T_BLK;           // the two blocks of one 32-wide chunk
+
+// Tile shapes.  A workgroup owns 16 TT token rows; its compute waves are TT token tiles x CP "chunk parities": wave (tw, cp) works on
+// the 32-wide chunks c = cp (mod CP) of token tile tw, a ring stage holds CP consecutive chunks (one per parity), and the CP partial
+// accumulators of a token tile are summed through LDS at the end (fixed order).  <12, 1>: 192 rows, for the decoder's M = B * 192.
+// <3, 2>: 48 rows (one encoder sample) when M is small — every workgroup streams ALL the weights (~12 us per 590 KB at the measured
+// ~50 GB/s per CU), so a short tile is weight-stream bound; the second parity halves the number of dependent chunk bodies
+// (~0.55 us each: LDS -> 6 chained MFMA steps -> GELU -> 12 MFMAs) that sit between two stage barriers.
+template <int TT, int CP> struct TileCfg {
+    static constexpr int NCW = TT * CP, THREADS = 64 * (NCW + T_DW), ROWS = 16 * TT;
+    static constexpr int STAGE = CP * T_CHUNK, NSTAGE = CP == 1 ? 4 : 3, RING = NSTAGE * STAGE;
+    static constexpr int PPW = 24 * CP / T_DW;                                    // DMA pieces per DMA wave and stage
+    static constexpr int RED0 = (CP - 1) * TT * 12 * 1024;                        // partial accumulators of the parities > 0 (aliases the ring)
+    static_assert(RED0 <= RING && TT * 3 * T_D * 4 <= RING, "reduction buffers reuse the ring");
+    static_assert(PPW == 6 || PPW == 12, "vmcnt immediates");
+};
+constexpr int PFD = 1;                       // fragment prefetch distance of the chunk bodies, in steps
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* gl_vp;
@@ -73,25 +86,30 @@ __device__ __forceinline__ void dma_f2_piece(const bf16* W, int ldw, int c0, int
     __builtin_amdgcn_global_load_lds((gl_vp)(W + (long)row * ldw + c0 + csrc * 8), (lds_vp)(dst + p * 1024), 16, 0, 0);
 }
 
-// the DMA waves' side of the ring: `nst` stages of two blocks each (24 pieces, 6 per DMA wave), NSTAGE = 3.  issue(s, dst, p) loads
-// piece p of stage s.  One barrier per stage, matched by the compute waves; `tail` extra barriers at the end.
-template <typename Issue>
-__device__ __forceinline__ void dma_ring(int dw, int nst, char* ring, Issue issue, int tail) {
+// the DMA waves' side of the ring: `nst` stages of CP chunks (PPW pieces per DMA wave), NSTAGE - 1 stages requested ahead.
+// issue(c, dst, p) loads piece p (0..23) of chunk c to the chunk image at dst.  One barrier per stage, matched by the compute waves;
+// `tail` extra barriers at the end.  Chunks past `nc` re-load the last chunk (same instruction count per stage: the counted waits hold).
+template <int TT, int CP, typename Issue>
+__device__ __forceinline__ void dma_ring(int dw, int nc, char* ring, Issue issue, int tail) {
+    using Cf = TileCfg<TT, CP>;
+    constexpr int LOOK = Cf::NSTAGE - 1;
+    const int nst = (nc + CP - 1) / CP;
     auto stage = [&](int s) {
-        char* dst = ring + (s % T_NSTAGE) * T_STAGE;
+        char* dst = ring + (s % Cf::NSTAGE) * Cf::STAGE;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) issue(s, dst, dw * 6 + j);
+        for (int j = 0; j < Cf::PPW; ++j) {
+            const int p = dw * Cf::PPW + j, q = p / 24;
+            issue(min(s * CP + q, nc - 1), dst + q * T_CHUNK, p % 24);
+        }
     };
-    stage(0);
-    if (nst > 1) stage(1);
-    if (nst > 2) stage(2);
+    for (int s = 0; s < LOOK && s < nst; ++s) stage(s);
     for (int s = 0; s < nst; ++s) {
-        // loads retire in order: stages s + 1 and s + 2 (6 pieces each per DMA wave) may remain in flight
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        const int ahead = min(LOOK - 1, nst - 1 - s);         // stages that may remain in flight (loads retire in order)
+        if (ahead * Cf::PPW >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ahead * Cf::PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                           // stage s landed; every compute wave is done with stage s - 1
-        if (s + 3 < nst) stage(s + 3);
+        __builtin_amdgcn_s_barrier();                         // stage s landed; every compute wave is done with stage s - 1
+        if (s + LOOK < nst) stage(s + LOOK);
     }
     for (int i = 0; i < tail; ++i) __builtin_amdgcn_s_barrier();
 }
@@ -106,71 +124,106 @@ __device__ __forceinline__ void load_tok_frags(const bf16* __restrict__ X, long 
     }
 }
 
+// sum of the CP partial accumulators of a token tile into its parity-0 wave (fixed order cp = 0, 1, ..): two barriers when CP > 1.
+// RED0: [CP - 1][TT][12 tiles][64 lanes] float4, aliasing the ring.
+template <int TT, int CP>
+__device__ __forceinline__ void reduce_to_parity0(char* RED, int tw, int cp, int lane, f32x4 (&yacc)[12]) {
+    if (CP == 1) return;
+    __builtin_amdgcn_s_barrier();                             // every wave is done with the ring (RED aliases it)
+    f32x4* R = reinterpret_cast<f32x4*>(RED);
+    if (cp > 0) {
+#pragma unroll
+        for (int d = 0; d < 12; ++d) R[(((cp - 1) * TT + tw) * 12 + d) * 64 + lane] = yacc[d];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (cp == 0) {
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+#pragma unroll
+            for (int q = 1; q < CP; ++q) yacc[d] += R[(((q - 1) * TT + tw) * 12 + d) * 64 + lane];
+        }
+    }
+}
+
 // =============================================================================================================================
 // Feed-forward half, forward:   u = xn2 W1^T + b1;  h = GELU(u);  xout = x1 + h W2^T + b2      (rows are independent: any M)
-// LDS: ring 4 x 24 KiB | b1 [mlp] f32 | b2 [192] f32
-struct MlpFwdLayout {
-    static constexpr int RING = 0, B1 = T_NSTAGE * T_STAGE;
+// LDS: ring 4 x 24 KiB (later RED) | b1 [mlp] f32 | b2 [192] f32
+template <int TT, int CP> struct MlpFwdLayout {
+    static constexpr int RING = 0, B1 = TileCfg<TT, CP>::RING;
     static size_t total(int mlp) { return (size_t)B1 + (size_t)mlp * 4 + T_D * 4; }
 };
 
-__global__ __launch_bounds__(T_THREADS) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+template <int TT, int CP>
+__global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                                    const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                    const bf16* __restrict__ W2, const float* __restrict__ b2, int M, int mlp,
                                                                    bf16* __restrict__ u_out, bf16* __restrict__ h_out,
                                                                    float* __restrict__ xout) {
+    using Cf = TileCfg<TT, CP>;
+    constexpr int NCW = Cf::NCW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* RING = smem + MlpFwdLayout::RING;
-    float* B1 = reinterpret_cast<float*>(smem + MlpFwdLayout::B1);
+    char* RING = smem + MlpFwdLayout<TT, CP>::RING;
+    float* B1 = reinterpret_cast<float*>(smem + MlpFwdLayout<TT, CP>::B1);
     float* B2 = B1 + mlp;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const long row0 = (long)blockIdx.x * T_TOK;
+    const long row0 = (long)blockIdx.x * Cf::ROWS;
     const int NC = mlp >> 5;                                  // 32-wide hidden chunks
+    const int NS = (NC + CP - 1) / CP;                        // ring stages
 
-    if (wave >= T_CW) {
-        dma_ring(wave - T_CW, NC, RING, [&](int c, char* dst, int p) {
+    if (wave >= NCW) {
+        dma_ring<TT, CP>(wave - NCW, NC, RING, [&](int c, char* dst, int p) {
             if (p < 12) dma_f1_piece(W1, T_D, 32 * c, p, dst, lane);              // W1 rows 32 c .. (hidden units of the chunk)
             else dma_f2_piece(W2, mlp, 32 * c, p - 12, dst + T_BLK, lane);        // W2 columns 32 c ..
-        }, 0);
+        }, CP > 1 ? 2 : 0);
         return;
     }
-    const long trow = row0 + 16 * wave + li;                  // this lane's token (column of every accumulator tile)
+    const int tw = wave % TT, cp = wave / TT;
+    const long trow = row0 + 16 * tw + li;                    // this lane's token (column of every accumulator tile)
     const bool ok = trow < M;
     Frag<bf16> xb[6];
     load_tok_frags(xn2, trow, ok, g, xb);
-    for (int id = tid; id < mlp; id += 64 * T_CW) B1[id] = b1[id];                // shared: the first ring barrier orders them
-    for (int id = tid; id < T_D; id += 64 * T_CW) B2[id] = b2[id];
+    for (int id = tid; id < mlp; id += 64 * NCW) B1[id] = b1[id];                 // shared: the first ring barrier orders them
+    for (int id = tid; id < T_D; id += 64 * NCW) B2[id] = b2[id];
 
     f32x4 yacc[12];
 #pragma unroll
     for (int d = 0; d < 12; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c = 0; c < NC; ++c) {
-        __builtin_amdgcn_s_barrier();                         // stage c landed
+    for (int st = 0; st < NS; ++st) {
+        __builtin_amdgcn_s_barrier();                         // stage st landed
         asm volatile("" ::: "memory");
-        const char* Wa = RING + (c % T_NSTAGE) * T_STAGE;
+        const int c = st * CP + cp;                           // this parity's chunk of the stage
+        if (c >= NC) continue;
+        const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE + cp * T_CHUNK;
         const char* Wb = Wa + T_BLK;
-        // Software-pipelined by hand: the fragments of step i + 1 are requested BEFORE the MFMAs of step i are issued, so the LDS pipe
-        // serves the next reads while the matrix pipe works (left alone, the compiler hoists all reads of a product to its top and
-        // waits once: with the 12 waves in lockstep behind the stage barrier, LDS time and MFMA time then ADD — measured 15 + 20 us).
+        // Software-pipelined by hand: 12 steps (6 k steps of fc1, then 6 pairs of output tiles of fc2), the two fragments of step
+        // i + PFD are requested before the MFMAs of step i are issued — the LDS pipe serves the next step while the matrix pipe works,
+        // and fc2's first fragments are in flight during the GELU.  (Left alone, the compiler hoists all reads of a product to its top
+        // and waits once: with the waves in lockstep behind the stage barrier LDS time and MFMA time then ADD.  PFD = 3 spills at the
+        // 128-VGPR cap of 16 waves per CU: 55 -> 105 us.)
         f32x4 ua[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        Frag<bf16> fa[2], fn[2];
-        fn[0] = frag_f1p(Wa, 0, 0, li, g);
-        fn[1] = frag_f1p(Wa, 1, 0, li, g);
+        Frag<bf16> fr[PFD][2];
+        auto req = [&](int step, Frag<bf16>(&dst)[2]) {
+            if (step < 6) {
+                dst[0] = frag_f1p(Wa, 0, step, li, g);
+                dst[1] = frag_f1p(Wa, 1, step, li, g);
+            } else {
+                dst[0] = frag_f2(Wb, 2 * (step - 6), li, g);
+                dst[1] = frag_f2(Wb, 2 * (step - 6) + 1, li, g);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) req(i, fr[i]);
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
-            fa[0] = fn[0]; fa[1] = fn[1];
-            if (ks + 1 < 6) {
-                fn[0] = frag_f1p(Wa, 0, ks + 1, li, g);
-                fn[1] = frag_f1p(Wa, 1, ks + 1, li, g);
-            } else {
-                fn[0] = frag_f2(Wb, 0, li, g);                // first fragments of the second product: in flight during the GELU
-                fn[1] = frag_f2(Wb, 1, li, g);
-            }
+            const Frag<bf16> a0 = fr[ks % PFD][0], a1 = fr[ks % PFD][1];
             asm volatile("" ::: "memory");
-            ua[0] = mma16(fa[0], xb[ks], ua[0]);
-            ua[1] = mma16(fa[1], xb[ks], ua[1]);
+            req(ks + PFD, fr[ks % PFD]);
+            asm volatile("" ::: "memory");
+            ua[0] = mma16(a0, xb[ks], ua[0]);
+            ua[1] = mma16(a1, xb[ks], ua[1]);
         }
         // bias, pre-activation rounded as the backward will read it, GELU.  Register r of tile t is hidden unit 32 c + 8 g + 4 t + r:
         // the lane's 8 values are consecutive -> one 16-byte piece of u and of h per token, and h is already the B fragment of fc2
@@ -192,19 +245,18 @@ __global__ __launch_bounds__(T_THREADS) void mlp_t192_fwd_kernel(const bf16* __r
             }
         }
 #pragma unroll
-        for (int d = 0; d < 12; d += 2) {
-            fa[0] = fn[0]; fa[1] = fn[1];
-            if (d + 2 < 12) {
-                fn[0] = frag_f2(Wb, d + 2, li, g);
-                fn[1] = frag_f2(Wb, d + 3, li, g);
-            }
+        for (int st2 = 6; st2 < 12; ++st2) {
+            const Frag<bf16> a0 = fr[st2 % PFD][0], a1 = fr[st2 % PFD][1];
             asm volatile("" ::: "memory");
-            yacc[d] = mma16(fa[0], hb, yacc[d]);
-            yacc[d + 1] = mma16(fa[1], hb, yacc[d + 1]);
+            if (st2 + PFD < 12) req(st2 + PFD, fr[st2 % PFD]);
+            asm volatile("" ::: "memory");
+            yacc[2 * (st2 - 6)] = mma16(a0, hb, yacc[2 * (st2 - 6)]);
+            yacc[2 * (st2 - 6) + 1] = mma16(a1, hb, yacc[2 * (st2 - 6) + 1]);
         }
     }
-    // xout = x1 + y + b2: a lane holds 4 consecutive columns of its token per tile
-    if (ok) {
+    // xout = x1 + y + b2: a lane holds 4 consecutive columns of its token per tile (parity 0 finishes the token tile)
+    reduce_to_parity0<TT, CP>(RING, tw, cp, lane, yacc);
+    if (ok && cp == 0) {
 #pragma unroll
         for (int d = 0; d < 12; ++d) {
             const int col = 16 * d + 4 * g;
@@ -214,37 +266,266 @@ __global__ __launch_bounds__(T_THREADS) void mlp_t192_fwd_kernel(const bf16* __r
     }
 }
 
+// =============================================================================================================================
+// Feed-forward half, backward (dgrad chain + LN2 backward; the weight gradients stay with wgrad.hip, which reads du and dx1_t):
+//     du   = (dx_t W2) * gelu'(u)                [M, mlp]  (+ column sums = fc1 bias gradient, one partial row per 192-row tile)
+//     dxn2 = du W1                                [M, D]    (fp32, never leaves the registers)
+//     dx1  = dx + LN2-backward(dxn2; x1, gamma2)  in place, + compute-type copy, + [3 D] partials (dgamma2 | dbeta2 | colsum dx1)
+// Ring stage c: F1 = rows 32 c .. of W2^T [mlp][D], F2 = columns 32 c .. of W1^T [D][mlp].
+// LDS: ring 4 x 24 KiB | CS [12][mlp] f32 column sums per wave | G [192] gamma      (LP [12][3 D] reuses the ring after the loop)
+template <int TT, int CP> struct MlpBwdLayout {
+    static constexpr int RING = 0, CS = TileCfg<TT, CP>::RING;
+    static size_t total(int mlp) { return (size_t)CS + (size_t)TT * mlp * 4 + T_D * 4; }
+};
+
+__device__ __forceinline__ float row16_sum_t(float v) {   // sum over the 16 lanes of a DPP row, every lane gets the total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+// sum over the 4 lane groups (lanes li, li + 16, li + 32, li + 48): the reduction over a token's columns that sit in other lanes
+__device__ __forceinline__ float col4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int TT, int CP>
+__global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+                                                                   const float* __restrict__ x1, const float* __restrict__ ln2_w,
+                                                                   const bf16* __restrict__ u, const bf16* __restrict__ W2T,
+                                                                   const bf16* __restrict__ W1T, float eps, int M, int mlp,
+                                                                   bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
+                                                                   float* __restrict__ cs_part, float* __restrict__ ln_part) {
+    using Cf = TileCfg<TT, CP>;
+    constexpr int NCW = Cf::NCW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem + MlpBwdLayout<TT, CP>::RING;
+    float* CS = reinterpret_cast<float*>(smem + MlpBwdLayout<TT, CP>::CS);     // [TT][mlp]: a chunk's sums come from one parity only
+    float* G = CS + TT * mlp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const long row0 = (long)blockIdx.x * Cf::ROWS;
+    const int NC = mlp >> 5;
+    const int NS = (NC + CP - 1) / CP;
+
+    if (wave >= NCW) {
+        dma_ring<TT, CP>(wave - NCW, NC, RING, [&](int c, char* dst, int p) {
+            if (p < 12) dma_f1_piece(W2T, T_D, 32 * c, p, dst, lane);
+            else dma_f2_piece(W1T, mlp, 32 * c, p - 12, dst + T_BLK, lane);
+        }, CP > 1 ? 5 : 3);
+        return;
+    }
+    const int tw = wave % TT, cp = wave / TT;
+    const long trow = row0 + 16 * tw + li;
+    const bool ok = trow < M;
+    Frag<bf16> db[6];
+    load_tok_frags(dxt, trow, ok, g, db);
+    for (int id = tid; id < T_D; id += 64 * NCW) G[id] = ln2_w[id];
+    float* CSw = CS + tw * mlp;
+
+    f32x4 yacc[12];
+#pragma unroll
+    for (int d = 0; d < 12; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 un = uint4{0u, 0u, 0u, 0u};                          // u of the lane's 8 hidden units of its next chunk (rows past M: 0)
+    if (ok && cp < NC) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * cp + 8 * g);
+
+    for (int st = 0; st < NS; ++st) {
+        __builtin_amdgcn_s_barrier();                         // stage st landed
+        asm volatile("" ::: "memory");
+        const int c = st * CP + cp;                           // this parity's chunk of the stage
+        if (c >= NC) continue;
+        const Frag<bf16> uc = {__builtin_bit_cast(bf16x8, un)};
+        if (ok && c + CP < NC) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * (c + CP) + 8 * g);
+        const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE + cp * T_CHUNK;
+        const char* Wb = Wa + T_BLK;
+        f32x4 ta[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        Frag<bf16> fr[PFD][2];                                // same 12-step pipeline as the forward
+        auto req = [&](int step, Frag<bf16>(&dst)[2]) {
+            if (step < 6) {
+                dst[0] = frag_f1p(Wa, 0, step, li, g);
+                dst[1] = frag_f1p(Wa, 1, step, li, g);
+            } else {
+                dst[0] = frag_f2(Wb, 2 * (step - 6), li, g);
+                dst[1] = frag_f2(Wb, 2 * (step - 6) + 1, li, g);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) req(i, fr[i]);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const Frag<bf16> a0 = fr[ks % PFD][0], a1 = fr[ks % PFD][1];
+            asm volatile("" ::: "memory");
+            req(ks + PFD, fr[ks % PFD]);
+            asm volatile("" ::: "memory");
+            ta[0] = mma16(a0, db[ks], ta[0]);
+            ta[1] = mma16(a1, db[ks], ta[1]);
+        }
+        // du = t * gelu'(u) for the lane's 8 consecutive hidden units (32 c + 8 g + j), rounded as the weight-gradient GEMM reads it;
+        // their sums over the wave's 16 tokens -> CS[token tile][hidden] (fc1 bias gradient partials, fixed order)
+        Frag<bf16> dub;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = j < 4 ? ta[0][j & 3] : ta[1][j & 3];
+            dub.v[j] = (bf16)(t * gelu_grad_fast((float)uc.v[j]));
+        }
+        if (ok) *reinterpret_cast<bf16x8*>(du_out + trow * mlp + 32 * c + 8 * g) = dub.v;
+        {
+            float cs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] = row16_sum_t(ok ? (float)dub.v[j] : 0.f);
+            if (li == 0) {
+                *reinterpret_cast<f32x4*>(CSw + 32 * c + 8 * g) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                *reinterpret_cast<f32x4*>(CSw + 32 * c + 8 * g + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+            }
+        }
+#pragma unroll
+        for (int st2 = 6; st2 < 12; ++st2) {
+            const Frag<bf16> a0 = fr[st2 % PFD][0], a1 = fr[st2 % PFD][1];
+            asm volatile("" ::: "memory");
+            if (st2 + PFD < 12) req(st2 + PFD, fr[st2 % PFD]);
+            asm volatile("" ::: "memory");
+            yacc[2 * (st2 - 6)] = mma16(a0, dub, yacc[2 * (st2 - 6)]);
+            yacc[2 * (st2 - 6) + 1] = mma16(a1, dub, yacc[2 * (st2 - 6) + 1]);
+        }
+    }
+    reduce_to_parity0<TT, CP>(RING, tw, cp, lane, yacc);     // (two barriers when CP > 1)
+    // ---- LN2 backward on the registers: the lane holds columns 16 d + 4 g + r of ITS token; token sums = registers + 2 shuffles.
+    // With CP parities the waves of parity 0 do it for their token tile; the others only keep the barrier count.
+    const bool lnw = (cp == 0);
+    f32x4 xh[12];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = (ok && lnw) ? *reinterpret_cast<const f32x4*>(x1 + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (xh[d][0] + xh[d][1]) + (xh[d][2] + xh[d][3]);
+    }
+    const float mean = col4_sum(s) * (1.0f / T_D);
+    float q = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = xh[d] - mean;
+        q += (xh[d][0] * xh[d][0] + xh[d][1] * xh[d][1]) + (xh[d][2] * xh[d][2] + xh[d][3] * xh[d][3]);
+    }
+    const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = xh[d] * rstd;
+        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + 16 * d + 4 * g);
+        s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
+        const f32x4 t = gd * xh[d];
+        s2 += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    s1 = col4_sum(s1) * (1.0f / T_D);
+    s2 = col4_sum(s2) * (1.0f / T_D);
+    __builtin_amdgcn_s_barrier();                             // T1: every wave is done with the ring (LP aliases it) and with CS
+    float* LP = reinterpret_cast<float*>(RING) + wave * 3 * T_D;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        const int col = 16 * d + 4 * g;
+        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
+        f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && lnw) {
+            rr = (gd - s1 - xh[d] * s2) * rstd + *reinterpret_cast<const f32x4*>(dx + trow * T_D + col);
+            *reinterpret_cast<f32x4*>(dx + trow * T_D + col) = rr;
+            bf16x4 pk;
+            pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
+            *reinterpret_cast<bf16x4*>(dx1t_out + trow * T_D + col) = pk;
+        }
+        f32x4 pg = yacc[d] * xh[d], pb = yacc[d], pc = rr;    // rows past M hold zeros in all three
+        if (!ok || !lnw) { pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pg[e] = row16_sum_t(pg[e]); pb[e] = row16_sum_t(pb[e]); pc[e] = row16_sum_t(pc[e]);
+        }
+        if (li == 0) {
+            *reinterpret_cast<f32x4*>(LP + col) = pg;
+            *reinterpret_cast<f32x4*>(LP + T_D + col) = pb;
+            *reinterpret_cast<f32x4*>(LP + 2 * T_D + col) = pc;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // T2: partials complete
+    {
+        const float* LP0 = reinterpret_cast<const float*>(RING);
+        for (int id = tid; id < 3 * T_D; id += 64 * NCW) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < TT; ++w) a += LP0[w * 3 * T_D + id];          // parity-0 waves are waves 0 .. TT - 1
+            ln_part[(long)blockIdx.x * 3 * T_D + id] = a;
+        }
+        for (int id = tid; id < mlp; id += 64 * NCW) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < TT; ++w) a += CS[w * mlp + id];
+            cs_part[(long)blockIdx.x * mlp + id] = a;
+        }
+    }
+    __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
+}
+
 }  // namespace
 
-// g_t192: -1 off, 1 on (default; M3L_T192=0 disables)
+// g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip)
 static int g_t192 = 0;
 static int t192_state() {
     if (!g_t192) {
         const char* e = getenv("M3L_T192");
-        g_t192 = (e && atoi(e) <= 0) ? -1 : 1;
+        g_t192 = e ? (atoi(e) > 0 ? atoi(e) : -1) : 1;
     }
     return g_t192;
 }
 extern "C" int m3l_set_t192(int on) {
-    const int old = t192_state() > 0 ? 1 : 0;
-    g_t192 = on > 0 ? 1 : -1;
+    const int old = t192_state() > 0 ? g_t192 : 0;
+    g_t192 = on > 0 ? on : -1;
     return old;
 }
+int m3l_mlp_t192_short(void) { return t192_state() > 0 && (g_t192 & 2); }
 
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M) {
     return t192_state() > 0 && dtype == 1 && D == T_D && mlp % 32 == 0 && mlp >= 32 && mlp <= 1024 && M > 0;
 }
 
+// tile shape for M rows: 192-row tiles while they give ~a workgroup per CU, 48-row tiles (two chunk parities) below that
+static int t192_tt(int M) { return cdiv(M, 192) >= 200 ? 12 : 3; }
+int m3l_mlp_t192_tiles(int M) { return cdiv(M, 16 * t192_tt(M)); }
+
+#define T192_DISPATCH(TTV, CALL)                                          \
+    if ((TTV) == 12) { constexpr int TT = 12, CP = 1; CALL; }             \
+    else { constexpr int TT = 3, CP = 2; CALL; }
+
 int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st) {
     static int inited = 0;
     if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout::total(1024)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<12, 1>::total(1024)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<3, 2>::total(1024)));
         inited = 1;
     }
-    ProfScope prof("mlp_t192_fwd", M, mlp, T_D, 4.0 * M * (double)T_D * mlp, st, (double)M * (T_D * 2.0 + T_D * 8.0 + mlp * 4.0));
-    mlp_t192_fwd_kernel<<<cdiv(M, T_TOK), T_THREADS, MlpFwdLayout::total(mlp), st>>>((const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M,
-                                                                                     mlp, (bf16*)u, (bf16*)h, xout);
+    const int tt = t192_tt(M);
+    ProfScope prof("mlp_t192_fwd", M, mlp, tt, 4.0 * M * (double)T_D * mlp, st, (double)M * (T_D * 2.0 + T_D * 8.0 + mlp * 4.0));
+    T192_DISPATCH(tt, (mlp_t192_fwd_kernel<TT, CP><<<cdiv(M, 16 * TT), TileCfg<TT, CP>::THREADS, MlpFwdLayout<TT, CP>::total(mlp), st>>>(
+                           (const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout)));
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u, const void* w2T,
+                     const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_bwd_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpBwdLayout<12, 1>::total(1024)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_bwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpBwdLayout<3, 2>::total(1024)));
+        inited = 1;
+    }
+    const int tt = t192_tt(M);
+    ProfScope prof("mlp_t192_bwd", M, mlp, tt, 4.0 * M * (double)T_D * mlp, st, (double)M * (T_D * 4.0 + T_D * 12.0 + mlp * 4.0));
+    T192_DISPATCH(tt, (mlp_t192_bwd_kernel<TT, CP><<<cdiv(M, 16 * TT), TileCfg<TT, CP>::THREADS, MlpBwdLayout<TT, CP>::total(mlp), st>>>(
+                           (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t,
+                           cs_part, ln_part)));
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -8,9 +8,10 @@
 //             bounds the MFMA rate;
 //   staging   both operands by bounds-checked LDS-DMA (buffer_load ... lds, rows >= M read as zero) issued from INLINE ASM: the
 //             compiler does not see the LDS write, so it does not drain vmcnt(0) in front of the next ds_read (it does for the
-//             builtin form: round 1's kernel waited for every prefetch before computing).  Two 64-row stages; the wave waits for
-//             its own pieces with s_waitcnt vmcnt(0) at the TOP of the next step, i.e. a whole MFMA block after issuing them;
-//   LDS image 64-column panels of [64 rows][128 B]; 16-byte chunk index XOR 2 ((row >> 1) & 3), applied on the per-lane SOURCE
+//             builtin form: round 1's kernel waited for every prefetch before computing).  Four 32-row stages, three requested
+//             ahead (~96 KiB in flight per CU: one stage ahead left every step waiting ~2 us for HBM); counted s_waitcnt vmcnt
+//             (4 pieces per wave and stage) + one barrier per stage;
+//   LDS image 64-column panels of [32 rows][128 B]; 16-byte chunk index XOR 2 ((row >> 1) & 3), applied on the per-lane SOURCE
 //             address (the DMA destination is lane-linear) and on the read: the 8 rows a half-wave's ds_read_b64_tr_b16 touches
 //             fall on 8 distinct 32-byte bank slots (conflict-free k-strided transpose reads);
 //   split-M   S = #CU / tiles row ranges (>= 1 workgroup per CU, <= 1 round), each writing its fp32 tile in FRAGMENT order (one
@@ -82,9 +83,12 @@ __device__ __forceinline__ Frag<bf16> ldtr(const char* panel, int k0, int c0, in
     return f;
 }
 
+constexpr int WG_NST = 4;                    // ring stages of 32 rows x 8 panels (32 KiB): three stages requested ahead
+constexpr int WG_STAGE = 8 * 4096;
+
 template <int TBT>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs) {
-    constexpr int TB = 64 * TBT, NP = 4 + TBT, STAGE = NP * 8192, NB = TB / 32, NT = 4 * NB;
+    constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -100,31 +104,38 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
     const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
     const int m_beg = sp * rows_per_split;
     const int m_end = min(M, m_beg + rows_per_split);
-    const int nsteps = (m_end - m_beg + 63) >> 6;
+    const int nst = (m_end - m_beg + 31) >> 5;               // 32-row stages
 
     const int4v rsA = make_rsrc(pb.A, (long)M * pb.lda * 2), rsB = make_rsrc(pb.B, (long)M * pb.ldb * 2);
-    // this wave's NP pieces of a stage: piece q = wave * NP + j = (panel q >> 3, row group q & 7); panels 0..3 = A, 4.. = B
-    unsigned voff[NP], vinc[NP];
+    // A stage image = 4 + TBT panels of [32 rows][128 B] (panels 0..3 = A, 4.. = B) in a 32-KiB slot.  Waves 0..3 stage one A panel
+    // each (4 pieces: its four 8-row groups); waves 4..7 stage 8-row group (wave - 4) of every B panel (TBT pieces): the counted
+    // waits below use each wave's own piece count.
+    const bool wave_a = wave < 4;                             // wave-uniform
+    unsigned voff[4], vinc;
+    unsigned pdst[4];
+    {
+        const int ld = wave_a ? pb.lda : pb.ldb;
+        vinc = (unsigned)(32 * ld * 2);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int q = wave * NP + j, panel = q >> 3, rg = q & 7;
-        const int row = rg * 8 + (lane >> 3);
-        const int csrc = (lane & 7) ^ (2 * ((row >> 1) & 3));
-        const bool isa = panel < 4;
-        const int ld = isa ? pb.lda : pb.ldb;
-        int col = isa ? (a0 + 64 * panel + csrc * 8) : (b0 + 64 * (panel - 4) + csrc * 8);
-        col = min(col, (isa ? pb.a : pb.b) - 8);              // columns past the operand: any valid chunk (never stored)
-        voff[j] = (unsigned)(((long)(m_beg + row) * ld + col) * 2);
-        vinc[j] = (unsigned)(64 * ld * 2);
+        for (int j = 0; j < 4; ++j) {
+            const int panel = wave_a ? wave : 4 + j, rg = wave_a ? j : wave - 4;
+            const int row = rg * 8 + (lane >> 3);
+            const int csrc = (lane & 7) ^ (2 * ((row >> 1) & 3));
+            int col = wave_a ? (a0 + 64 * panel + csrc * 8) : (b0 + 64 * j + csrc * 8);
+            col = min(col, (wave_a ? pb.a : pb.b) - 8);       // columns past the operand: any valid chunk (never stored)
+            voff[j] = (unsigned)(((long)(m_beg + row) * ld + col) * 2);
+            pdst[j] = (unsigned)(panel * 4096 + rg * 1024);
+        }
     }
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int st, int t) {
+    auto issue = [&](int t) {
+        const unsigned base = lds0 + (t % WG_NST) * WG_STAGE;
+        if (wave_a) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int q = wave * NP + j;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + q * 1024);
-            if ((q >> 3) < 4) dma16(rsA, voff[j] + (unsigned)t * vinc[j], dst);
-            else dma16(rsB, voff[j] + (unsigned)t * vinc[j], dst);
+            for (int j = 0; j < 4; ++j) dma16(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < TBT; ++j) dma16(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
         }
     };
 
@@ -134,30 +145,40 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
 #pragma unroll
         for (int y = 0; y < NB; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nsteps > 0) issue(0, 0);
-    for (int t = 0; t < nsteps; ++t) {
-        const int cur = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t (issued one MFMA block ago) have landed
-        __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done reading the other stage
-        asm volatile("" ::: "memory");
-        if (t + 1 < nsteps) issue(cur ^ 1, t + 1);
-        const char* As = smem + cur * STAGE + wr * 8192;
-        const char* Bs = smem + cur * STAGE + 4 * 8192;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Frag<bf16> fa[4], fb[NB];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) fa[x] = ldtr(As, ks * 32, x * 16, lane);
-#pragma unroll
-            for (int y = 0; y < NB; ++y) {
-                const int col = wc * (TB / 2) + y * 16;
-                fb[y] = ldtr(Bs + (col >> 6) * 8192, ks * 32, col & 63, lane);
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < NB; ++y) acc[x][y] = mma16(fa[x], fb[y], acc[x][y]);
+    for (int t = 0; t < WG_NST - 1 && t < nst; ++t) issue(t);
+    for (int t = 0; t < nst; ++t) {
+        // this wave's pieces of stage t have landed once at most the pieces of the (up to two) younger stages remain (in-order retire)
+        const int ahead = min(WG_NST - 2, nst - 1 - t);
+        if (wave_a || TBT == 4) {
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (TBT == 3) {
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done reading stage t - 1
+        asm volatile("" ::: "memory");
+        if (t + WG_NST - 1 < nst) issue(t + WG_NST - 1);      // into the slot stage t - 1 occupied
+        const char* As = smem + (t % WG_NST) * WG_STAGE + wr * 4096;
+        const char* Bs = smem + (t % WG_NST) * WG_STAGE + 4 * 4096;
+        Frag<bf16> fa[4], fb[NB];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[x] = ldtr(As, 0, x * 16, lane);
+#pragma unroll
+        for (int y = 0; y < NB; ++y) {
+            const int col = wc * (TB / 2) + y * 16;
+            fb[y] = ldtr(Bs + (col >> 6) * 4096, 0, col & 63, lane);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) acc[x][y] = mma16(fa[x], fb[y], acc[x][y]);
     }
     // fragment-order slab: [wave][tile x * NB + y][lane] float4 (rows 4 g .. 4 g + 3 of the 16 x 16 tile, column li)
     float* S = slabs + ((long)sp * grp.tiles_total + gtile) * (long)(WG_TA * TB);
@@ -195,14 +216,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const fl
     const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
     const long stride = (long)grp.tiles_total * (WG_TA * TB);
     const float* P = slabs + (long)gt * (WG_TA * TB) + ((long)f << 2);
-    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    // 8 independent 16-byte loads in flight per thread (the loop over a run-time S with two accumulators issued them in pairs: 13
+    // dependent round trips for S = 25); the sum order is fixed: ((s0 + s1) + (s2 + s3)) + ... over i mod 8, then the tail
+    f32x4 a8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     int i = 0;
-    for (; i + 1 < S; i += 2) {
-        s0 += *reinterpret_cast<const f32x4*>(P + (long)i * stride);
-        s1 += *reinterpret_cast<const f32x4*>(P + (long)(i + 1) * stride);
+    for (; i + 8 <= S; i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += *reinterpret_cast<const f32x4*>(P + (long)(i + k) * stride);
     }
-    if (i < S) s0 += *reinterpret_cast<const f32x4*>(P + (long)i * stride);
-    s0 += s1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (i + k < S) a8[k] += *reinterpret_cast<const f32x4*>(P + (long)(i + k) * stride);
+    f32x4 s0 = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     const int lane = f & 63, wt = f >> 6, t = wt % NT, w = wt / NT, x = t / NB, y = t % NB;
     const int ia = a0 + (w >> 1) * 64 + x * 16 + 4 * (lane >> 4);
     const int ib = b0 + (w & 1) * (TB / 2) + y * 16 + (lane & 15);
@@ -288,9 +315,9 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
                    int extra_count) {
     static int inited = 0;
     if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 6 * 8192));
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 8192));
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8192));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
         inited = 1;
     }
     M3L_CHECK(count >= 1 && count <= M3L_TN_MAX_PROBLEMS && M > 0, "wgrad: count=%d M=%d", count, M);
@@ -320,7 +347,7 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
     {
         ProfScope prof("wgrad", M, pl.tiles_total, pl.S, flops, st, bytes + (double)pl.ws_bytes);
         const dim3 g1(8 * pl.tiles_total * cdiv(pl.S, 8));
-        const size_t lds = (size_t)2 * (4 + pl.tbt) * 8192;
+        const size_t lds = (size_t)WG_NST * WG_STAGE;
         if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
         else if (pl.tbt == 3) wgrad_kernel<3><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
         else wgrad_kernel<4><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);

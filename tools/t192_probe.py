@@ -8,7 +8,7 @@ from m3l_amd import _lib as L
 LIBP = sys.argv[1] if len(sys.argv) > 1 else L.LIB_PATH
 raw = C.CDLL(LIBP)
 dev = "cuda:0"
-M, D, mlp = 49152, 192, 768
+M, D, mlp = int(os.environ.get("PM", "49152")), 192, 768
 xn2 = torch.randn(M, D, device=dev).bfloat16()
 x1 = torch.randn(M, D, device=dev)
 w1 = (torch.randn(mlp, D, device=dev) * 0.05).bfloat16()

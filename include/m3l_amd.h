@@ -21,6 +21,12 @@
  *   m3l_layernorm_*        nn.LayerNorm (models/VTT.py:354 final norm of the DINO-style encoder)
  *   m3l_vt_load            utils/pretrain_utils.py:7-57 (NHWC -> NCHW, per-sensor channel pick, [-1,1] -> [0,1])
  */
+/* Threading / device contract.  One process per GPU (the torch.distributed model) with ONE host thread driving a device's steps:
+ * entry points are asynchronous on the caller's HIP stream, allocate nothing, and keep no state except (a) the thread-local error
+ * string, (b) a per-device low-priority side stream + event ring (weight gradients, weight casts), created on first use under a
+ * mutex, and (c) process-wide tuning switches (m3l_set_attn_block / m3l_set_t192 / m3l_set_rowln) and one-time kernel-attribute
+ * initialisation for the first device used.  A second device in the same process, or two threads stepping one device concurrently,
+ * are outside the contract. */
 #ifndef M3L_AMD_H
 #define M3L_AMD_H
 #include <stddef.h>
@@ -166,6 +172,11 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 /* obs (B, H, W, 3*fs) f32 NHWC -> image (B, 3*fs, H, W); tactile (B, 3*S*fs, h, w) -> per-sensor (B, 3*fs, h, w), (x+1)/2 */
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream);
+/* the same with the observation dtype (0 = f32, 1 = uint8: raw camera / sensor frames, no host-side cast) and the reference's
+ * normalisation arguments: out = (x - lo) / (hi - lo), fp32 IEEE arithmetic as utils/pretrain_utils.py:28-30,47-49 */
+int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
+                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+                 float* const* tactile_out, void* stream);
 
 /* ---- torch.optim.Adam semantics (models/ppo_mae.py:182-183) over one flat fp32 buffer of n elements; step counts from 1 */
 int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,

@@ -453,22 +453,25 @@ __global__ void adam_bias_kernel(int* __restrict__ step, float b1, float b2, flo
     bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
 }
 
-// vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW (normalisation [0,1] is the identity);
-// tactile (B, 3*S*fs, h, w): sensor s takes channels {f*3S + 3s + c}, value (x + 1) / 2
-__global__ void vt_image_kernel(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out) {
+// vt_load (utils/pretrain_utils.py:7-57): image NHWC -> NCHW; tactile (B, 3*S*fs, h, w): sensor s takes channels {f*3S + 3s + c};
+// both normalised as the reference writes it, (x - lo) / (hi - lo) in fp32 with an IEEE division (defaults [0, 1] = identity and
+// [-1, 1] = (x + 1) / 2, both exact).  TI = float or uint8_t (torch.Tensor(uint8 array) converts exactly).
+template <typename TI>
+__global__ void vt_image_kernel(const TI* __restrict__ in, int B, int H, int W, int C, float lo, float span, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * C * H * W) return;
     const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((long)W * H)) % C), b = (int)(i / ((long)W * H * C));
-    out[i] = in[(((long)b * H + h) * W + w) * C + c];
+    out[i] = __fdiv_rn((float)in[(((long)b * H + h) * W + w) * C + c] - lo, span);
 }
 struct VtTactileOut { float* p[M3L_MAX_SENSORS]; };
-__global__ void vt_tactile_kernel(const float* __restrict__ in, int B, int th, int tw, int S, int fs, VtTactileOut o) {
+template <typename TI>
+__global__ void vt_tactile_kernel(const TI* __restrict__ in, int B, int th, int tw, int S, int fs, float lo, float span, VtTactileOut o) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int CH = 3 * S * fs;
     if (i >= (long)B * CH * th * tw) return;
     const int px = (int)(i % ((long)th * tw)), ch = (int)((i / ((long)th * tw)) % CH), b = (int)(i / ((long)th * tw * CH));
     const int f = ch / (3 * S), r = ch % (3 * S), s = r / 3, c = r % 3;
-    o.p[s][(((long)b * 3 * fs) + f * 3 + c) * th * tw + px] = (in[i] + 1.0f) * 0.5f;
+    o.p[s][(((long)b * 3 * fs) + f * 3 + c) * th * tw + px] = __fdiv_rn((float)in[i] - lo, span);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1089,19 +1092,30 @@ int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_de
     return 0;
 }
 
-int m3l_vt_load_launch(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
-                       int n_sensors, int frame_stack, float* const* tactile_out, hipStream_t st) {
+int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
+                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+                       float* const* tactile_out, hipStream_t st) {
     if (image_nhwc) {
+        M3L_CHECK(img_hi != img_lo, "vt_load: empty image normalisation range");
         const long total = (long)B * C * H * W;
-        vt_image_kernel<<<cdiv(total, 256), 256, 0, st>>>(image_nhwc, B, H, W, C, image_nchw);
+        if (image_u8)
+            vt_image_kernel<uint8_t><<<cdiv(total, 256), 256, 0, st>>>((const uint8_t*)image_nhwc, B, H, W, C, img_lo, img_hi - img_lo, image_nchw);
+        else
+            vt_image_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)image_nhwc, B, H, W, C, img_lo, img_hi - img_lo, image_nchw);
         M3L_LAUNCH_CHECK();
     }
     if (tactile) {
         M3L_CHECK(n_sensors >= 1 && n_sensors <= M3L_MAX_SENSORS, "vt_load: n_sensors=%d", n_sensors);
+        M3L_CHECK(tac_hi != tac_lo, "vt_load: empty tactile normalisation range");
         VtTactileOut o;
         for (int s = 0; s < n_sensors; ++s) o.p[s] = tactile_out[s];
         const long total = (long)B * 3 * n_sensors * frame_stack * th * tw;
-        vt_tactile_kernel<<<cdiv(total, 256), 256, 0, st>>>(tactile, B, th, tw, n_sensors, frame_stack, o);
+        if (tactile_u8)
+            vt_tactile_kernel<uint8_t><<<cdiv(total, 256), 256, 0, st>>>((const uint8_t*)tactile, B, th, tw, n_sensors, frame_stack, tac_lo,
+                                                                         tac_hi - tac_lo, o);
+        else
+            vt_tactile_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)tactile, B, th, tw, n_sensors, frame_stack, tac_lo,
+                                                                       tac_hi - tac_lo, o);
         M3L_LAUNCH_CHECK();
     }
     return 0;

@@ -173,8 +173,9 @@ int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
 int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
 int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
-int m3l_vt_load_launch(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
-                       int n_sensors, int frame_stack, float* const* tactile_out, hipStream_t st);
+int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
+                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+                       float* const* tactile_out, hipStream_t st);
 struct ConvSrc {
     const void* src[M3L_MAX_SENSORS];   // nchw: f32 [B, Ci, H, W] per source (sources concatenated on batch); else one NHWC compute-type [Btot*H*W, Ci]
     int nsrc, nchw;

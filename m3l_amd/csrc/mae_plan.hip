@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/m3l_amd.h"
@@ -25,13 +27,21 @@ struct SideStream {
     hipStream_t s = nullptr;
     std::vector<hipEvent_t> ev;
     int next = 0;
-    int device = -1;
 };
-SideStream g_side;
+// one side stream + event ring per DEVICE (created on first use, never destroyed), guarded by a mutex: two host threads that drive
+// two devices get their own; two threads on ONE device share the stream and take events under the lock (the contract of the header
+// — one host thread per device drives a step — is what keeps the event ring from being recycled under a waiter)
+std::mutex g_side_mu;
+std::map<int, SideStream> g_sides;
+thread_local SideStream* t_side = nullptr;
+#define g_side (*t_side)
 int side_init() {
     int dev = 0;
     M3L_HIP(hipGetDevice(&dev));
-    if (g_side.s && g_side.device == dev) return 0;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    SideStream& ss = g_sides[dev];
+    t_side = &ss;
+    if (ss.s) return 0;
     // LOWEST stream priority, for two reasons.  (1) The work is off the critical path (weight gradients, next layers' weight
     // casts).  (2) HIP multiplexes streams of one priority class onto a small pool of hardware queues; once a process holds
     // many streams (torch's stream pool after torch.distributed initialises RCCL) a normal-priority side stream lands on the
@@ -39,13 +49,13 @@ int side_init() {
     // its own queue pool and nothing else in a torch process uses the lowest one.
     int prio_least = 0, prio_greatest = 0;
     M3L_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    M3L_HIP(hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_least));
-    g_side.device = dev;
-    g_side.ev.resize(64);
-    for (auto& e : g_side.ev) M3L_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    M3L_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio_least));
+    ss.ev.resize(64);
+    for (auto& e : ss.ev) M3L_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
 hipEvent_t side_event() {
+    std::lock_guard<std::mutex> lock(g_side_mu);
     hipEvent_t e = g_side.ev[g_side.next];
     g_side.next = (g_side.next + 1) % (int)g_side.ev.size();
     return e;
@@ -1207,7 +1217,14 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 }
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream) {
-    return m3l_vt_load_launch(image_nhwc, B, H, W, C, image_nchw, tactile, th, tw, n_sensors, frame_stack, tactile_out, (hipStream_t)stream);
+    return m3l_vt_load_launch(image_nhwc, 0, B, H, W, C, 0.f, 1.f, image_nchw, tactile, 0, th, tw, n_sensors, frame_stack, -1.f, 1.f, tactile_out,
+                              (hipStream_t)stream);
+}
+int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
+                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+                 float* const* tactile_out, void* stream) {
+    return m3l_vt_load_launch(image_nhwc, image_u8, B, H, W, C, img_lo, img_hi, image_nchw, tactile, tactile_u8, th, tw, n_sensors, frame_stack,
+                              tac_lo, tac_hi, tactile_out, (hipStream_t)stream);
 }
 
 int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,

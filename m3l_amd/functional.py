@@ -82,20 +82,51 @@ def mask_sample(geom: L.Geom, ratio: float, noises, counts=None):
 
 
 def _grad_targets(sink, params, used=None):
-    """Where the native backward writes parameter gradients.
-    sink None  -> fresh zero tensors, returned to autograd (which accumulates into .grad: reference semantics).
-    sink given -> (GradSync, bucket): the parameters' .grad are views into the sync's flat buffer; the kernels write
-                  them in place (overwrite) and autograd gets None for them (no per-tensor accumulate / copy kernels)."""
+    """Where the native backward writes parameter gradients -> (targets, direct).
+    sink None  -> fresh zero tensors, returned to autograd (which accumulates into .grad: reference semantics); direct = False.
+    sink given -> (GradSync, bucket): the parameters' .grad are views into the sync's flat buffer; the kernels write them in place
+                  (overwrite) and autograd gets None for them (no per-tensor accumulate / copy kernels); direct = True.
+    A SECOND backward through the same parameters before GradSync.zero_grad() (the reference's `separate_optimizer=False` update,
+    ppo_mae.py:249-266, runs mae_loss.backward() and then the policy loss through MAEExtractor -> get_embeddings; micro-batch
+    accumulation does the same) must ADD: it takes the autograd route (fresh tensors, accumulated into the flat views by autograd).
+    When the sync communicates, the first gradient has already been all-reduced, so that is an error instead of a silent divergence."""
+    direct = sink is not None
+    if direct:
+        sync = sink[0]
+        ids = [id(p) for i, p in enumerate(params)
+               if p is not None and (used is None or used[i]) and getattr(p, "grad", None) is not None and p.requires_grad]
+        if any(i in sync._written for i in ids):
+            if sync._comm:
+                raise RuntimeError("GradSync: second backward through the same parameters before zero_grad() while gradients are being "
+                                   "all-reduced (the first ones have already travelled); call finish() + step() + zero_grad() per backward, "
+                                   "or build the GradSync without communication for gradient accumulation")
+            direct = False
+        else:
+            sync._written.update(ids)
     out = []
     for i, p in enumerate(params):
         ok = p is not None and (used is None or used[i])
         if not ok:
             out.append(None)
-        elif sink is not None and getattr(p, "grad", None) is not None and p.requires_grad:
+        elif direct and getattr(p, "grad", None) is not None and p.requires_grad:
             out.append(p.grad)
         else:
             out.append(torch.zeros_like(p))
-    return out
+    return out, direct
+
+
+def _versions(tensors):
+    return [None if t is None else t._version for t in tensors]
+
+
+def _check_versions(ctx, what):
+    """The Functions keep references to the live parameters and compute-type copies made in forward (not save_for_backward): an
+    in-place update between forward and backward (optimizer.step(), load_state_dict) would silently mix old and new weights, so it is
+    refused the way autograd refuses it."""
+    for i, (t, v) in enumerate(zip(ctx.params, ctx.versions)):
+        if t is not None and t._version != v:
+            raise RuntimeError(f"{what}: parameter {i} was modified by an inplace operation between forward and backward "
+                               f"(version {t._version}, expected {v})")
 
 
 def _returned(sink, grads):
@@ -105,6 +136,26 @@ def _returned(sink, grads):
 def _done(sink):
     if sink is not None and sink[1] is not None:      # bucket None: this Function only contributes part of a bucket
         sink[0].bucket_done(sink[1])
+
+
+def _pos_grads(pos_img, pos_tac, dtokens, idx):
+    """Gradient of the LEARNED position rows (use_sincosmod_encodings=False, pretrain_models.py:218-219,280-287): position j receives
+    the sum over the batch of the token gradients that sit at position j.  (None, None) when the positions are fixed sincos buffers.
+    dtokens (B, L, D) f32; idx (B, L) int64 positions of the L tokens, or None when all positions are present in order."""
+    want_i = pos_img is not None and pos_img.requires_grad
+    want_t = pos_tac is not None and pos_tac.requires_grad
+    if not (want_i or want_t):
+        return None, None
+    n_img = pos_img.shape[0] if pos_img is not None else 0
+    n_all = n_img + (pos_tac.shape[0] if pos_tac is not None else 0)
+    if idx is None:
+        dense = dtokens
+    else:
+        B, K, D = dtokens.shape
+        dense = torch.zeros(B, n_all, D, dtype=torch.float32, device=dtokens.device)
+        L.check(L.lib().m3l_scatter_tokens(L.ptr(dtokens), B, n_all, D, L.ptr(idx.contiguous()), K, L.ptr(dense), _stream()), "m3l_scatter_tokens")
+    g = dense.sum(dim=0)
+    return (g[:n_img] if want_i else None), (g[n_img:n_all] if want_t else None)
 
 
 # -------------------------------------------------------------------------------------------------------------------
@@ -126,21 +177,26 @@ class EmbedFn(torch.autograd.Function):
                                       L.ptr_array(tens), L.ptr(ws), L.ptr(tokens), _stream()), "m3l_embed_fwd")
         ctx.saved = (geom, D, dt, idx, cnt_img, L_tok, image, tactiles, tens, ws)
         ctx.params, ctx.sink = tensors, sink
+        ctx.versions = _versions(tensors)
         return tokens
 
     @staticmethod
     def backward(ctx, dtokens):
+        _check_versions(ctx, "EmbedFn")
         geom, D, dt, idx, cnt_img, L_tok, image, tactiles, tens, ws = ctx.saved
         B = dtokens.shape[0]
         dtokens = _f32c(dtokens)
         # parameters of a modality that is absent from this call stay without gradient (as in the reference graph)
         used = [image is not None] * 6 + [len(tactiles) > 0] * 6 + [True, False, False]
-        grads = _grad_targets(ctx.sink, ctx.params, used)
+        grads, direct = _grad_targets(ctx.sink, ctx.params, used)
+        sink = ctx.sink if direct else None
         L.check(L.lib().m3l_embed_bwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image),
                                       L.ptr_array(tactiles), L.ptr_array(tens), L.ptr(ws), L.ptr(dtokens),
                                       L.ptr_array(grads), _stream()), "m3l_embed_bwd")
-        _done(ctx.sink)
-        return (None,) * 9 + _returned(ctx.sink, grads)
+        _done(sink)
+        out = list(_returned(sink, grads))
+        out[13], out[14] = _pos_grads(ctx.params[13], ctx.params[14], dtokens, idx)
+        return (None,) * 9 + tuple(out)
 
 
 class TransformerFn(torch.autograd.Function):
@@ -161,6 +217,7 @@ class TransformerFn(torch.autograd.Function):
                                             L.ptr(y_t), L.ptr(y32), _stream()), "m3l_transformer_fwd")
         ctx.saved = (cfg, x, tens, ws)
         ctx.params, ctx.sink = tensors, sink
+        ctx.versions = _versions(tensors)
         ctx.set_materialize_grads(False)     # an unused output must arrive as None in backward, not as a zero tensor to add and convert
         if y_t is None:
             y_t = y32.clone()     # f32 compute: two distinct autograd outputs over the same values
@@ -168,6 +225,7 @@ class TransformerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy_t, dy32):
+        _check_versions(ctx, "TransformerFn")
         cfg, x, tens, ws = ctx.saved
         B, n, D = x.shape
         if dy_t is None and dy32 is None:         # nothing downstream used this stack
@@ -179,9 +237,9 @@ class TransformerFn(torch.autograd.Function):
             code = DT_BF16 if dy.dtype == torch.bfloat16 else DT_F32
         else:
             dy, code = _f32c(dy32), DT_F32
-        grads = _grad_targets(ctx.sink, ctx.params)
+        grads, direct = _grad_targets(ctx.sink, ctx.params)
         dx = torch.empty_like(x)
-        sink = ctx.sink
+        sink = ctx.sink if direct else None
         chunk = BWD_CHUNK_LAYERS
         if chunk is None and sink is not None and sink[1] is not None and sink[0]._comm:
             chunk = sink[0].layers_per_chunk
@@ -219,10 +277,12 @@ class UnshuffleFn(torch.autograd.Function):
                                           _stream()), "m3l_unshuffle_fwd")
         ctx.saved = (geom, D, dd, dt, unmasked, masked, enc_t, tens, ws)
         ctx.params, ctx.sink = tensors, sink
+        ctx.versions = _versions(tensors)
         return dec_in
 
     @staticmethod
     def backward(ctx, d_dec_in):
+        _check_versions(ctx, "UnshuffleFn")
         geom, D, dd, dt, unmasked, masked, enc_t, tens, ws = ctx.saved
         B, nvis = unmasked.shape
         nmask = masked.shape[1]
@@ -230,15 +290,18 @@ class UnshuffleFn(torch.autograd.Function):
         d_dec_in = _f32c(d_dec_in)
         proj = tens[0] is not None
         d_enc = torch.empty(B, nvis, D, dtype=(tdtype(dt) if proj else torch.float32), device=dev)
-        grads = _grad_targets(ctx.sink, ctx.params, [True, True, True, True, False, False])
+        grads, direct = _grad_targets(ctx.sink, ctx.params, [True, True, True, True, False, False])
+        sink = ctx.sink if direct else None
         code = C.c_int(0)
         L.check(L.lib().m3l_unshuffle_bwd(C.byref(geom), D, dd, dt, B, nvis, nmask, L.ptr(unmasked), L.ptr(masked),
                                           L.ptr(enc_t), L.ptr_array(tens), L.ptr(ws), L.ptr(d_dec_in), L.ptr(d_enc),
                                           C.byref(code), L.ptr_array(grads), _stream()), "m3l_unshuffle_bwd")
-        _done(ctx.sink)
+        _done(sink)
+        out = list(_returned(sink, grads))
+        out[4], out[5] = _pos_grads(ctx.params[4], ctx.params[5], d_dec_in, None)      # learned decoder positions (decoder_pos_emb)
         if proj:      # gradient flows through the compute-type encoder output
-            return (None,) * 7 + (d_enc, None) + _returned(ctx.sink, grads)
-        return (None,) * 7 + (None, d_enc) + _returned(ctx.sink, grads)
+            return (None,) * 7 + (d_enc, None) + tuple(out)
+        return (None,) * 7 + (None, d_enc) + tuple(out)
 
 
 class HeadsLossFn(torch.autograd.Function):
@@ -272,20 +335,23 @@ class HeadsLossFn(torch.autograd.Function):
         ctx.saved = (geom, dd, dt, masked, nm_img, tens, ws, (B, N), dec_t.dtype)
         ctx.used = [image is not None] * 2 + [len(tactiles) > 0] * 2
         ctx.params, ctx.sink = tensors, sink
+        ctx.versions = _versions(tensors)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
+        _check_versions(ctx, "HeadsLossFn")
         geom, dd, dt, masked, nm_img, tens, ws, (B, N), ddtype = ctx.saved
         nmask = masked.shape[1]
         dloss = _f32c(dloss)
         d_dec = torch.empty(B, N, dd, dtype=ddtype, device=dloss.device)
-        grads = _grad_targets(ctx.sink, ctx.params, ctx.used)
+        grads, direct = _grad_targets(ctx.sink, ctx.params, ctx.used)
+        sink = ctx.sink if direct else None
         L.check(L.lib().m3l_heads_loss_bwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr_array(tens),
                                            L.ptr(ws), L.ptr(dloss), L.ptr(d_dec), L.ptr_array(grads), _stream()),
                 "m3l_heads_loss_bwd")
-        _done(ctx.sink)
-        return (None,) * 9 + (d_dec,) + _returned(ctx.sink, grads)
+        _done(sink)
+        return (None,) * 9 + (d_dec,) + _returned(sink, grads)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -361,17 +427,19 @@ class EarlyCnnFn(torch.autograd.Function):
                                          _stream()), "m3l_earlycnn_fwd")
         ctx.saved = (cfg, B, nsrc, srcs, tens, ws)
         ctx.params, ctx.sink = tensors, sink
+        ctx.versions = _versions(tensors)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         cfg, B, nsrc, srcs, tens, ws = ctx.saved
         dout = _f32c(dout)
-        grads = _grad_targets(ctx.sink, ctx.params)
+        grads, direct = _grad_targets(ctx.sink, ctx.params)
+        sink = ctx.sink if direct else None
         L.check(L.lib().m3l_earlycnn_bwd(C.byref(cfg), B, nsrc, L.ptr_array(tens), L.ptr(ws), L.ptr(dout), L.ptr_array(grads),
                                          _stream()), "m3l_earlycnn_bwd")
-        _done(ctx.sink)
-        return (None, None, None) + _returned(ctx.sink, grads)
+        _done(sink)
+        return (None, None, None) + _returned(sink, grads)
 
 
 class TokensAssembleFn(torch.autograd.Function):
@@ -391,6 +459,7 @@ class TokensAssembleFn(torch.autograd.Function):
                                                 L.ptr(tokens), _stream()), "m3l_tokens_assemble_fwd")
         ctx.saved = (geom, D, B, None if img_tok is None else img_tok.shape, None if tac_tok is None else tac_tok.shape)
         ctx.params, ctx.sink = (mod,), sink
+        ctx.pos = (pos_img, pos_tac)
         return tokens
 
     @staticmethod
@@ -400,10 +469,11 @@ class TokensAssembleFn(torch.autograd.Function):
         dev = dtok.device
         d_img = torch.empty(ishape, dtype=torch.float32, device=dev) if ishape is not None else None
         d_tac = torch.empty(tshape, dtype=torch.float32, device=dev) if tshape is not None else None
-        (gmod,) = _grad_targets(ctx.sink, ctx.params)
+        (gmod,), direct = _grad_targets(ctx.sink, ctx.params)
+        sink = ctx.sink if direct else None
         gmod.zero_()                                  # rows of sensors absent from this call keep a zero gradient
         ws = _ws(L.lib().m3l_tokens_assemble_ws_bytes(C.byref(geom), D), dev)
         L.check(L.lib().m3l_tokens_assemble_bwd(C.byref(geom), D, B, L.ptr(dtok), L.ptr(d_img), L.ptr(d_tac), L.ptr(ws), L.ptr(gmod),
                                                 _stream()), "m3l_tokens_assemble_bwd")
-        _done(ctx.sink)
-        return (None, None, None, d_img, d_tac) + _returned(ctx.sink, [gmod]) + (None, None)
+        _done(sink)
+        return (None, None, None, d_img, d_tac) + _returned(sink, [gmod]) + _pos_grads(ctx.pos[0], ctx.pos[1], dtok, None)

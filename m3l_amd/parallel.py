@@ -44,6 +44,9 @@ class GradSync:
     SKIP = ("encoder.pos_embedding", "decoder_pos_emb.weight")
 
     def __init__(self, module: torch.nn.Module, process_group=None, force_comm=False):
+        if not getattr(module, "use_sincosmod_encodings", True):
+            raise NotImplementedError("GradSync lays the flat buffer out for use_sincosmod_encodings=True (the learned position tables "
+                                      "receive their gradient through autograd, after the bucket they would belong to is reported done)")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_comm: issue the collectives even at world size 1 (rehearses the RCCL stream / event path on a one-GPU box)
@@ -86,6 +89,7 @@ class GradSync:
         self.buckets.append([start, off, count])
         self._works = []
         self._reduced = set()
+        self._written = set()                                  # id(param) written directly by a backward since zero_grad()
         self.params = [p for _, p in named]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
@@ -97,6 +101,7 @@ class GradSync:
     def zero_grad(self):
         self.flat.zero_()
         self._reduced = set()
+        self._written = set()
         self._ready, self._sent_end = [], 0
 
     # The flat buffer is laid out in the order the backward finishes (heads -> decoder top-down -> glue -> encoder top-down ->

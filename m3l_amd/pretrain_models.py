@@ -190,8 +190,6 @@ class VTMAE(nn.Module):
                  num_tactiles=2, early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=1, compute_dtype="fp32"):
         super().__init__()
         assert masking_ratio > 0 and masking_ratio < 1, 'masking ratio must be kept between 0 and 1'
-        if not use_sincosmod_encodings:
-            raise NotImplementedError("use_sincosmod_encodings=False (learned positions) is not built in the HIP path")
         self.masking_ratio = masking_ratio
         self.num_tactiles = num_tactiles
         self.frame_stack = frame_stack
@@ -232,6 +230,10 @@ class VTMAE(nn.Module):
 
         self.encoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), encoder_dim)
         self.decoder_modality_embedding = nn.Embedding((1 + self.num_tactiles), decoder_dim)
+        # use_sincosmod_encodings=False (:218-219,280-287): the kernels still add "modality + position" per token; the modality term is
+        # this zero table and the position term a slice of the learned table (not part of the state dict)
+        self.register_buffer('_zero_mod_enc', torch.zeros(1 + self.num_tactiles, encoder_dim), persistent=False)
+        self.register_buffer('_zero_mod_dec', torch.zeros(1 + self.num_tactiles, decoder_dim), persistent=False)
         self.set_compute_dtype(compute_dtype)
         self._sinks = {}            # bucket name -> (GradSync, bucket id), filled by m3l_amd.parallel.GradSync
         self.last_mask = None       # (masked_indices, unmasked_indices) of the latest forward, int64 (B, *)
@@ -244,16 +246,32 @@ class VTMAE(nn.Module):
         self.decoder.compute_dtype = compute_dtype
         return self
 
-    def _embed_tensors(self):
+    def _enc_positions(self, geom):
+        """(modality table, image positions, tactile positions) the embed kernels add: the sincos buffers, or — learned mode — rows
+        1.. of encoder.pos_embedding in the order of the tokens PRESENT in this call (pretrain_models.py:218-219)."""
+        if self.use_sincosmod_encodings:
+            return self.encoder_modality_embedding.weight, self.image_enc_pos_embedding[0], self.tactile_enc_pos_embedding[0]
+        c = Fn.mask_counts(geom, self.masking_ratio)
+        k = geom.num_tactiles if geom.use_tactile else 0
+        n_img = c["n_img"]
+        pe = self.encoder.pos_embedding[0]
+        return self._zero_mod_enc, pe[1:1 + n_img], pe[1 + n_img:1 + n_img + k * c["n_tac"]]
+
+    def _embed_tensors(self, geom):
         i, t = self.encoder.image_to_patch_embedding, self.encoder.tactile_to_patch_embedding
         return [i[1].weight, i[1].bias, i[2].weight, i[2].bias, i[3].weight, i[3].bias,
-                t[1].weight, t[1].bias, t[2].weight, t[2].bias, t[3].weight, t[3].bias,
-                self.encoder_modality_embedding.weight, self.image_enc_pos_embedding[0], self.tactile_enc_pos_embedding[0]]
+                t[1].weight, t[1].bias, t[2].weight, t[2].bias, t[3].weight, t[3].bias, *self._enc_positions(geom)]
 
-    def _glue_tensors(self):
+    def _glue_tensors(self, geom):
         e2d = isinstance(self.enc_to_dec, nn.Linear)
-        return [self.enc_to_dec.weight if e2d else None, self.enc_to_dec.bias if e2d else None, self.mask_token,
-                self.decoder_modality_embedding.weight, self.image_dec_pos_embedding[0], self.tactile_dec_pos_embedding[0]]
+        if self.use_sincosmod_encodings:
+            pos = [self.decoder_modality_embedding.weight, self.image_dec_pos_embedding[0], self.tactile_dec_pos_embedding[0]]
+        else:       # decoder_pos_emb(unmasked_indices) / (masked_indices): position j of the present tokens gets row j (:280-287)
+            c = Fn.mask_counts(geom, self.masking_ratio)
+            k = geom.num_tactiles if geom.use_tactile else 0
+            w = self.decoder_pos_emb.weight
+            pos = [self._zero_mod_dec, w[:c["n_img"]], w[c["n_img"]:c["n_img"] + k * c["n_tac"]]]
+        return [self.enc_to_dec.weight if e2d else None, self.enc_to_dec.bias if e2d else None, self.mask_token, *pos]
 
     def _head_tensors(self):
         return [self.to_pixels.weight, self.to_pixels.bias, self.to_tactiles.weight, self.to_tactiles.bias]
@@ -275,8 +293,7 @@ class VTMAE(nn.Module):
         part = (self._sinks["embed"][0], None) if "embed" in self._sinks else None     # three Functions share the embed bucket
         img_tok = self.early_conv_vision.run([image], self.compute_dtype, part) if image is not None else None
         tac_tok = self.early_conv_tactile.run(tactiles, self.compute_dtype, part) if tactiles else None
-        return Fn.TokensAssembleFn.apply(part, geom, self.encoder_dim, img_tok, tac_tok, self.encoder_modality_embedding.weight,
-                                         self.image_enc_pos_embedding[0], self.tactile_enc_pos_embedding[0])
+        return Fn.TokensAssembleFn.apply(part, geom, self.encoder_dim, img_tok, tac_tok, *self._enc_positions(geom))
 
     def _tokens(self, geom, image, tactiles, idx, cnt_img, L_tok):
         dt = Fn.dtype_code(self.compute_dtype)
@@ -284,7 +301,7 @@ class VTMAE(nn.Module):
             tokens = self._stem_tokens(geom, image, tactiles)
             return tokens if idx is None else Fn.GatherTokensFn.apply(tokens, idx)
         return Fn.EmbedFn.apply(self._sinks.get("embed"), geom, self.encoder_dim, dt, idx, cnt_img, L_tok, image, tactiles,
-                                *self._embed_tensors())
+                                *self._embed_tensors(geom))
 
     # ------------------------------------------------------------------------------------------------------------
     def _step(self, x, use_vision, use_tactile, mask_noise, dump, counts=None):
@@ -303,7 +320,7 @@ class VTMAE(nn.Module):
         tokens = self._tokens(geom, image, tactiles, unmasked, nvis_img, c["num_unmasked"])
         enc_t, enc32 = self.encoder.transformer.run(tokens)
         dec_in = Fn.UnshuffleFn.apply(self._sinks.get("glue"), geom, self.encoder_dim, self.decoder_dim, dt, unmasked, masked,
-                                      enc_t, enc32, *self._glue_tensors())
+                                      enc_t, enc32, *self._glue_tensors(geom))
         dec_t, _ = self.decoder.run(dec_in)
         if self.early_conv_masking:
             # pretrain_models.py:311-322: predict ALL patches, loss over all of them (same kernel, identity index list)

@@ -116,15 +116,16 @@ def mask_indices(noises: List[np.ndarray], ratio: float, n_img: int, n_tac: int,
 # ----------------------------------------------------------------------------------------------------
 # float work (torch CPU)
 # ----------------------------------------------------------------------------------------------------
-def vt_load(obs: Dict[str, np.ndarray], frame_stack: int = 1) -> Dict[str, torch.Tensor]:
-    """utils/pretrain_utils.py:7-57 (image_normalization [0,1], tactile_normalization [-1,1])."""
+def vt_load(obs: Dict[str, np.ndarray], frame_stack: int = 1, image_normalization=(0, 1), tactile_normalization=(-1, 1)) -> Dict[str, torch.Tensor]:
+    """utils/pretrain_utils.py:7-57: NHWC -> NCHW, per-sensor channel pick, (x - lo) / (hi - lo) in fp32 (:28-30,47-49)."""
     out = {}
     if "image" in obs:
         img = np.asarray(obs["image"])
         if img.ndim == 3:
             img = img[None]
         assert img.shape[-1] == 3 * frame_stack
-        out["image"] = torch.tensor(img, dtype=torch.float32).permute(0, 3, 1, 2)
+        t = torch.tensor(img, dtype=torch.float32).permute(0, 3, 1, 2)
+        out["image"] = (t - image_normalization[0]) / (image_normalization[1] - image_normalization[0])
     if "tactile" in obs:
         tac = np.asarray(obs["tactile"])
         if tac.ndim == 3:
@@ -134,7 +135,7 @@ def vt_load(obs: Dict[str, np.ndarray], frame_stack: int = 1) -> Dict[str, torch
         idx = np.array([i * n_tactiles + c for i in range(frame_stack) for c in range(3)])
         for s in range(n_tactiles // 3):
             t = torch.tensor(tac[:, idx + 3 * s], dtype=torch.float32)
-            out[f"tactile{s + 1}"] = (t + 1.0) / 2.0
+            out[f"tactile{s + 1}"] = (t - tactile_normalization[0]) / (tactile_normalization[1] - tactile_normalization[0])
     return out
 
 
@@ -202,16 +203,18 @@ def early_cnn(x, P, prefix: str, key: str):
     return F.conv2d(x, P[prefix + "conv4.weight"], P[prefix + "conv4.bias"]).flatten(2).transpose(1, 2)
 
 
-def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=True, use_tactile=True):
+def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=True, use_tactile=True, sincos=True):
     """patchify + embed (or EarlyCNN stem when the parameters hold one) + modality + sincos for ALL patches
-    (pretrain_models.py:154-216)."""
+    (pretrain_models.py:154-216); sincos=False is `use_sincosmod_encodings=False`: no modality / sincos terms, the learned
+    `encoder.pos_embedding[:, 1:num_patches + 1]` added to the concatenated tokens instead (:218-219)."""
     dt = P["mask_token"].dtype
     early = "early_conv_vision.conv1.weight" in P
     toks, img_patches, tac_patches = [], None, None
     if use_vision:
         img_patches = patchify(x["image"].to(dt), cfg.image_patch)
         t = early_cnn(x["image"].to(dt), P, "early_conv_vision.", "image") if early else _embed(img_patches, P, "encoder.image_to_patch_embedding")
-        t = t + P["encoder_modality_embedding.weight"][0] + P["image_enc_pos_embedding"][0]
+        if sincos:
+            t = t + P["encoder_modality_embedding.weight"][0] + P["image_enc_pos_embedding"][0]
         toks.append(t)
     if cfg.num_tactiles > 0 and use_tactile:
         tac_patches = torch.cat([patchify(x[f"tactile{i + 1}"].to(dt), cfg.tactile_patch) for i in range(cfg.num_tactiles)], 1)
@@ -219,19 +222,25 @@ def encoder_tokens(P, cfg: OracleCfg, x: Dict[str, torch.Tensor], use_vision=Tru
             t = torch.cat([early_cnn(x[f"tactile{i + 1}"].to(dt), P, "early_conv_tactile.", "tactile") for i in range(cfg.num_tactiles)], 1)
         else:
             t = _embed(tac_patches, P, "encoder.tactile_to_patch_embedding")
-        mod = P["encoder_modality_embedding.weight"][1:1 + cfg.num_tactiles].repeat_interleave(cfg.n_tac, 0)
-        t = t + mod + P["tactile_enc_pos_embedding"][0]
+        if sincos:
+            mod = P["encoder_modality_embedding.weight"][1:1 + cfg.num_tactiles].repeat_interleave(cfg.n_tac, 0)
+            t = t + mod + P["tactile_enc_pos_embedding"][0]
         toks.append(t)
-    return torch.cat(toks, 1), img_patches, tac_patches
+    tokens = torch.cat(toks, 1)
+    if not sincos:
+        tokens = tokens + P["encoder.pos_embedding"][:, 1:tokens.shape[1] + 1]
+    return tokens, img_patches, tac_patches
 
 
 def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch.Tensor],
-                  noises: List[torch.Tensor], use_vision=True, use_tactile=True, perms=None, counts=None) -> Dict[str, torch.Tensor]:
-    """VTMAE.forward (pretrain_models.py:146-342), early_conv_masking=False, use_sincosmod_encodings=True.
+                  noises: List[torch.Tensor], use_vision=True, use_tactile=True, perms=None, counts=None,
+                  sincos=True) -> Dict[str, torch.Tensor]:
+    """VTMAE.forward (pretrain_models.py:146-342).  sincos=False = `use_sincosmod_encodings=False`: learned encoder positions
+    (:218-219) and `decoder_pos_emb` at every decoder position (:280-281,286-287) instead of the modality + sincos terms.
     Returns every intermediate the fixtures record plus 'loss'."""
     nt = cfg.num_tactiles if use_tactile else 0
     n_img = cfg.n_img if use_vision else 0
-    tokens, img_patches, tac_patches = encoder_tokens(P, cfg, x, use_vision, use_tactile)
+    tokens, img_patches, tac_patches = encoder_tokens(P, cfg, x, use_vision, use_tactile, sincos)
     B = tokens.shape[0]
     masked, unmasked, nm_img, nm_tac = mask_indices([np.asarray(z) for z in noises], cfg.ratio, n_img, cfg.n_tac, nt, perms, counts)
     masked_t, unmasked_t = torch.from_numpy(masked), torch.from_numpy(unmasked)
@@ -245,12 +254,15 @@ def vtmae_forward(P: Dict[str, torch.Tensor], cfg: OracleCfg, x: Dict[str, torch
     full = torch.zeros(B, N, cfg.dec_dim, dtype=tokens.dtype)
     full = full.index_put((br, unmasked_t), dec_in)
     full = full.index_put((br, masked_t), P["mask_token"].expand(B, masked_t.shape[1], -1))
-    add = []
-    if use_vision:
-        add.append(P["decoder_modality_embedding.weight"][0] + P["image_dec_pos_embedding"][0])
-    if nt > 0:
-        add.append(P["decoder_modality_embedding.weight"][1:1 + nt].repeat_interleave(cfg.n_tac, 0) + P["tactile_dec_pos_embedding"][0])
-    full = full + torch.cat(add, 0)
+    if sincos:
+        add = []
+        if use_vision:
+            add.append(P["decoder_modality_embedding.weight"][0] + P["image_dec_pos_embedding"][0])
+        if nt > 0:
+            add.append(P["decoder_modality_embedding.weight"][1:1 + nt].repeat_interleave(cfg.n_tac, 0) + P["tactile_dec_pos_embedding"][0])
+        full = full + torch.cat(add, 0)
+    else:
+        full = full + P["decoder_pos_emb.weight"][:N]       # decoder_pos_emb(unmasked_indices) / (masked_indices): every position j gets row j
     out["decoder_in"] = full
     dec = transformer(full, P, "decoder.", cfg.dec_depth, cfg.dec_heads, cfg.dec_dim_head)
     out["decoder_out"] = dec
@@ -322,9 +334,9 @@ def reconstruct(P, cfg: OracleCfg, x, noises, mask_ratio=None, use_vision=True, 
     return out
 
 
-def get_embeddings(P, cfg: OracleCfg, x, use_vision=True, use_tactile=True):
+def get_embeddings(P, cfg: OracleCfg, x, use_vision=True, use_tactile=True, sincos=True):
     """VTMAE.get_embeddings (pretrain_models.py:588-668): encoder over ALL tokens, no masking."""
-    tokens, _, _ = encoder_tokens(P, cfg, x, use_vision, use_tactile)
+    tokens, _, _ = encoder_tokens(P, cfg, x, use_vision, use_tactile, sincos)
     return transformer(tokens, P, "encoder.transformer.", cfg.depth, cfg.heads, cfg.dim_head)
 
 
@@ -387,6 +399,10 @@ def vtt_dino_forward(P, *, image_patch: int, tactile_patch: int, depth: int, hea
     if masks is not None:
         e1, e2, e3 = apply_masks(e1, masks), apply_masks(e2, masks), apply_masks(e3, masks)
     t = torch.cat([e1, e2, e3], dim=1)
+    nreg = 0
+    if "register_tokens" in P:                                # models/VTT.py:305-312: register tokens lead the sequence
+        nreg = P["register_tokens"].shape[1]
+        t = torch.cat([P["register_tokens"].expand(t.shape[0], -1, -1), t], dim=1)
     pre = transformer(t, P, "transformer.", depth, heads, dim_head)
     xn = F.layer_norm(pre, (D,), P["norm.weight"], P["norm.bias"], 1e-6)
-    return {"x_prenorm": pre, "x_norm_patchtokens": xn}
+    return {"x_prenorm": pre, "x_norm_patchtokens": xn[:, nreg:], "x_norm_regtokens": xn[:, :nreg]}

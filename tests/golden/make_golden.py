@@ -108,14 +108,14 @@ def _noise(gen, B, n, tie_row=None):
 
 
 def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp, C, num_tactiles,
-             dec_dim, dec_depth, dec_heads, ratio, B, seed, with_embeddings=False, early_conv=False):
+             dec_dim, dec_depth, dec_heads, ratio, B, seed, with_embeddings=False, early_conv=False, sincos=True):
     torch.manual_seed(seed)
     enc = ref.VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp_,
                   dim=dim, depth=depth, heads=heads, mlp_dim=mlp, image_channels=C, tactile_channels=C,
                   num_tactiles=num_tactiles)
     mae = ref.VTMAE(encoder=enc, decoder_dim=dec_dim, masking_ratio=ratio, decoder_depth=dec_depth,
                     decoder_heads=dec_heads, num_tactiles=num_tactiles, early_conv_masking=early_conv,
-                    use_sincosmod_encodings=True)
+                    use_sincosmod_encodings=sincos)
     # make LN affine / biases non-trivial so that every parameter is exercised
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
@@ -176,6 +176,7 @@ def run_case(ref, name, *, image_hw, tactile_hw, ip, tp_, dim, depth, heads, mlp
     out["ratio"] = np.array(ratio, dtype=np.float64)
     out["unused_params"] = np.array([k for k, p in mae.named_parameters() if p.grad is None])
     out["early_conv"] = np.array(int(early_conv))
+    out["sincos"] = np.array(int(sincos))
 
     if with_embeddings:
         with torch.no_grad():
@@ -349,9 +350,16 @@ def run_vt_load(ref):
         out.update({"out/" + k: v.numpy() for k, v in o.items()})
         np.savez_compressed(os.path.join(HERE, f"vt_load_fs{fs}.npz"), **out)
         print(f"vt_load_fs{fs}: keys={sorted(o.keys())}")
+    # uint8 camera frames + non-default normalisation ranges (utils/pretrain_utils.py:28-30,47-49)
+    obs = {"image": g.integers(0, 256, (2, 8, 8, 6), dtype=np.uint8), "tactile": (g.random((2, 12, 4, 4), dtype=np.float32) * 5 - 2)}
+    o = pu.vt_load({k: v.copy() for k, v in obs.items()}, image_normalization=[0, 255], tactile_normalization=[-2, 3], frame_stack=2)
+    out = {"in/" + k: v for k, v in obs.items()}
+    out.update({"out/" + k: v.numpy() for k, v in o.items()})
+    np.savez_compressed(os.path.join(HERE, "vt_load_u8.npz"), **out)
+    print(f"vt_load_u8: keys={sorted(o.keys())} image dtype {o['image'].dtype}")
 
 
-def run_vtt_dino():
+def run_vtt_dino(num_register_tokens=0, name="vtt_dino_small", seed=21):
     """DINO-style encoder `models/VTT.py:77-426` (forward / forward_features / prepare_tokens_with_masks),
     `SinusoidalEmbed` (tactile_ssl/model/layers/patch_embed.py:133-224) and `apply_masks`
     (tactile_ssl/utils/__init__.py:25-36).  `tactile_ssl/model/__init__.py` pulls torchvision through
@@ -364,15 +372,17 @@ def run_vtt_dino():
     spec = importlib.util.spec_from_file_location("ref_VTT", os.path.join(REF, "models", "VTT.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    torch.manual_seed(21)
+    torch.manual_seed(seed)
     B, D = 2, 64
     enc = m.VTT(image_size=32, tactile_size=32, image_patch_size=8, tactile_patch_size=8, dim=D, depth=2, heads=2,
-                mlp_dim=128, num_tactiles=2, num_register_tokens=0)
-    g = torch.Generator().manual_seed(22)
+                mlp_dim=128, num_tactiles=2, num_register_tokens=num_register_tokens)
+    g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for n_, p in enc.named_parameters():
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn(p.shape, generator=g))
+        if num_register_tokens:                 # the reference initialises them with std 1e-6: make them matter in the fixture
+            enc.register_tokens.add_(0.5 * torch.randn(enc.register_tokens.shape, generator=g))
     x = {k: torch.rand(B, 3, 32, 32, generator=g) for k in ("image", "tactile1", "tactile2")}
     masks = [torch.stack([torch.randperm(16, generator=g)[:5] for _ in range(B)]),
              torch.stack([torch.randperm(16, generator=g)[:5] for _ in range(B)])]
@@ -386,14 +396,16 @@ def run_vtt_dino():
     out["mask/0"], out["mask/1"] = masks[0].numpy(), masks[1].numpy()
     out["pos_embed"] = pos.numpy()
     out["full/x_norm_patchtokens"] = full["x_norm_patchtokens"].numpy()
+    out["full/x_norm_regtokens"] = full["x_norm_regtokens"].numpy()
     out["full/x_prenorm"] = full["x_prenorm"].numpy()
     out["masked/x_norm_patchtokens"] = mk.numpy()
     emb = torch.rand(B, 16, 8, generator=g)
     out["apply_masks/in"] = emb.numpy()
     out["apply_masks/out"] = m.apply_masks(emb, masks).numpy()
     out["meta"] = np.array([32, 8, D, 2, 2, 128, B], dtype=np.int64)
-    np.savez_compressed(os.path.join(HERE, "vtt_dino_small.npz"), **out)
-    print("vtt_dino_small: patchtokens", tuple(mk.shape), "pos", tuple(pos.shape))
+    out["num_register_tokens"] = np.array(num_register_tokens, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name + ": patchtokens", tuple(mk.shape), "pos", tuple(pos.shape), "registers", num_register_tokens)
 
 
 def _ref_layers():
@@ -468,6 +480,16 @@ def main():
     if "--block-only" in sys.argv:
         run_block_stack()
         return
+    if "--vtload-only" in sys.argv:
+        run_vt_load(ref)
+        return
+    if "--dinoreg-only" in sys.argv:
+        run_vtt_dino(num_register_tokens=4, name="vtt_dino_reg", seed=23)
+        return
+    if "--learnedpos-only" in sys.argv:
+        run_case(ref, "vt_learnedpos", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=1, heads=2, mlp=128, C=3,
+                 num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=16, with_embeddings=True, sincos=False)
+        return
     if "--extractor-only" in sys.argv:
         run_extractor(ref)
         run_dino_cat_extractor()
@@ -499,8 +521,12 @@ def _main_cases(ref):
     # E: the reference's DEFAULT flag early_conv_masking=True (EarlyCNN stem, loss over all patches), mask 0.95
     run_case(ref, "vt_earlyconv", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=1, heads=2, mlp=128, C=3,
              num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=15, with_embeddings=True, early_conv=True)
+    # G: use_sincosmod_encodings=False (learned encoder positions, decoder_pos_emb at every decoder position; :218-219,280-287)
+    run_case(ref, "vt_learnedpos", image_hw=32, tactile_hw=16, ip=8, tp_=4, dim=64, depth=1, heads=2, mlp=128, C=3,
+             num_tactiles=2, dec_dim=64, dec_depth=1, dec_heads=2, ratio=0.75, B=3, seed=16, with_embeddings=True, sincos=False)
     run_vt_load(ref)
     run_vtt_dino()
+    run_vtt_dino(num_register_tokens=4, name="vtt_dino_reg", seed=23)      # models/VTT.py:166-172,305-312
     run_block_stack()
 
 

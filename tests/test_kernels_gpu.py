@@ -177,3 +177,17 @@ def test_vt_load_matches_golden(dev, golden_dir):
         for k, v in out.items():
             assert v.dtype == torch.float32 and v.is_cuda
             np.testing.assert_array_equal(v.cpu().numpy(), z["out/" + k])
+    # uint8 frames go to the device as bytes; non-default normalisation ranges: bit-exact with the reference's fp32 arithmetic
+    z = np.load(os.path.join(golden_dir, "vt_load_u8.npz"))
+    assert z["in/image"].dtype == np.uint8
+    out = vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, image_normalization=[0, 255], tactile_normalization=[-2, 3], frame_stack=2)
+    for k, v in out.items():
+        np.testing.assert_array_equal(v.cpu().numpy(), z["out/" + k])
+    # a path argument: .npz of arrays is accepted, the reference's pickled .npy is refused with an explanation
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, "obs.npz"), image=z["in/image"], tactile=z["in/tactile"])
+        out2 = vt_load(os.path.join(d, "obs.npz"), image_normalization=[0, 255], tactile_normalization=[-2, 3], frame_stack=2)
+        assert all(torch.equal(out2[k], out[k]) for k in out)
+        with pytest.raises(NotImplementedError, match="unpickling is refused"):
+            vt_load(os.path.join(d, "obs.npy"))

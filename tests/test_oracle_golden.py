@@ -8,7 +8,11 @@ import torch
 
 from oracle import vtmae_oracle as O
 
-CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv"]
+CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv", "vt_learnedpos"]
+
+
+def _sincos(z):
+    return bool(int(z["sincos"])) if "sincos" in z.files else True
 
 
 def _load(golden_dir, name):
@@ -70,8 +74,8 @@ def test_forward_intermediates_and_loss(golden_dir, name):
     x, noises = _inputs(z)
     perms = [z[f"argsort/{i}"] for i in range(len(noises))]     # the permutations of THIS reference run
     with torch.no_grad():
-        r = O.vtmae_forward(P, cfg, x, noises, perms=perms)
-        r_stable = O.vtmae_forward(P, cfg, x, noises)
+        r = O.vtmae_forward(P, cfg, x, noises, perms=perms, sincos=_sincos(z))
+        r_stable = O.vtmae_forward(P, cfg, x, noises, sincos=_sincos(z))
     # tie order only permutes rows inside the masked lists here -> the loss must not depend on it
     assert abs(float(r_stable["loss"]) - float(r["loss"])) <= 1e-6 * abs(float(r["loss"]))
     tol = dict(rtol=1e-5, atol=2e-6)
@@ -91,7 +95,7 @@ def test_backward_grads(golden_dir, name):
     cfg = O.cfg_from_meta(z["meta"], z["ratio"])
     P = O.load_fixture_params(z, requires_grad=True)
     x, noises = _inputs(z)
-    O.vtmae_forward(P, cfg, x, noises)["loss"].backward()
+    O.vtmae_forward(P, cfg, x, noises, sincos=_sincos(z))["loss"].backward()
     unused = set(str(u) for u in z["unused_params"])
     checked = 0
     for k in z.files:
@@ -110,14 +114,14 @@ def test_backward_grads(golden_dir, name):
         assert P[u].grad is None, u
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv", "vt_learnedpos"])
 def test_get_embeddings(golden_dir, name):
     z = _load(golden_dir, name)
     cfg = O.cfg_from_meta(z["meta"], z["ratio"])
     P = O.load_fixture_params(z)
     x, _ = _inputs(z)
     with torch.no_grad():
-        e = O.get_embeddings(P, cfg, x)
+        e = O.get_embeddings(P, cfg, x, sincos=_sincos(z))
     np.testing.assert_allclose(e.numpy(), z["embeddings"], rtol=1e-4, atol=2e-5)
 
 
@@ -128,6 +132,13 @@ def test_vt_load(golden_dir, fs):
     assert sorted(out.keys()) == sorted(k[4:] for k in z.files if k.startswith("out/"))
     for k, v in out.items():
         assert v.dtype == torch.float32
+        np.testing.assert_array_equal(v.numpy(), z["out/" + k])
+
+
+def test_vt_load_uint8_and_ranges(golden_dir):
+    z = _load(golden_dir, "vt_load_u8")            # uint8 image, normalisation [0, 255] / [-2, 3], frame_stack 2
+    out = O.vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, frame_stack=2, image_normalization=[0, 255], tactile_normalization=[-2, 3])
+    for k, v in out.items():
         np.testing.assert_array_equal(v.numpy(), z["out/" + k])
 
 
@@ -142,8 +153,9 @@ def test_sincos_buffers_match_reference_buffers(golden_dir):
     np.testing.assert_allclose(tac.numpy(), z["param/tactile_enc_pos_embedding"][0], atol=1e-6)
 
 
-def test_dino_style_vtt(golden_dir):
-    z = _load(golden_dir, "vtt_dino_small")
+@pytest.mark.parametrize("fixture", ["vtt_dino_small", "vtt_dino_reg"])
+def test_dino_style_vtt(golden_dir, fixture):
+    z = _load(golden_dir, fixture)
     hw, p, D, depth, heads, mlp, B = [int(v) for v in z["meta"]]
     P = O.load_fixture_params(z)
     x = {k[len("input/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("input/")}
@@ -156,6 +168,9 @@ def test_dino_style_vtt(golden_dir):
     np.testing.assert_allclose(full["x_prenorm"].numpy(), z["full/x_prenorm"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(full["x_norm_patchtokens"].numpy(), z["full/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(mk["x_norm_patchtokens"].numpy(), z["masked/x_norm_patchtokens"], rtol=1e-4, atol=2e-5)
+    if fixture == "vtt_dino_reg":                              # num_register_tokens = 4 (models/VTT.py:166-172,305-312)
+        assert full["x_norm_regtokens"].shape[1] == 4 == int(z["num_register_tokens"])
+        np.testing.assert_allclose(full["x_norm_regtokens"].numpy(), z["full/x_norm_regtokens"], rtol=1e-4, atol=2e-5)
 
 
 RECON = ["recon_small", "recon_default_ratio", "recon_earlyconv"]

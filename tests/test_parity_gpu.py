@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from m3l_amd import VTMAE, VTT  # noqa: E402
 from oracle import vtmae_oracle as O  # noqa: E402
 
-CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv"]
+CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv", "vt_learnedpos"]
 DEV = "cuda:0"
 
 
@@ -23,7 +23,8 @@ def build_from_fixture(z, compute_dtype="fp32"):
     enc = VTT(image_size=image_hw, tactile_size=tactile_hw, image_patch_size=ip, tactile_patch_size=tp, dim=dim, depth=depth,
               heads=heads, mlp_dim=mlp, image_channels=C, tactile_channels=C, num_tactiles=k)
     mae = VTMAE(encoder=enc, decoder_dim=dd, masking_ratio=float(z["ratio"]), decoder_depth=ddepth, decoder_heads=dheads,
-                num_tactiles=k, compute_dtype=compute_dtype, early_conv_masking=bool(int(z["early_conv"])))
+                num_tactiles=k, compute_dtype=compute_dtype, early_conv_masking=bool(int(z["early_conv"])),
+                use_sincosmod_encodings=bool(int(z["sincos"])) if "sincos" in z.files else True)
     sd = {k_[len("param/"):]: torch.tensor(z[k_]) for k_ in z.files if k_.startswith("param/")}
     mae.load_state_dict(sd, strict=True)
     return mae.to(DEV)
@@ -84,7 +85,7 @@ def test_golden_fp32(golden_dir, name):
         assert dict(mae.named_parameters())[str(u)].grad is None, u
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv", "vt_learnedpos"])
 def test_golden_bf16_loss(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     mae = build_from_fixture(z, compute_dtype="bf16")
@@ -99,7 +100,7 @@ def test_golden_bf16_loss(golden_dir, name):
     assert cos > 0.99, cos
 
 
-@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv"])
+@pytest.mark.parametrize("name", ["vt_small", "vt_decdim", "vt_earlyconv", "vt_learnedpos"])
 def test_golden_get_embeddings(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     mae = build_from_fixture(z)
@@ -236,13 +237,16 @@ def test_direct_grad_mode_matches_autograd_mode():
             assert p.grad is None, n
 
 
-def test_dino_style_vtt_matches_reference_fixture(golden_dir):
-    """models/VTT.py forward / forward_features (with and without keep-index masks) vs the reference's own outputs."""
+@pytest.mark.parametrize("fixture", ["vtt_dino_small", "vtt_dino_reg"])
+def test_dino_style_vtt_matches_reference_fixture(golden_dir, fixture):
+    """models/VTT.py forward / forward_features (with and without keep-index masks; without and with 4 register tokens, :166-172,
+    305-312) vs the reference's own outputs."""
     from m3l_amd import DinoVTT
-    z = np.load(os.path.join(golden_dir, "vtt_dino_small.npz"))
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
     hw, p, D, depth, heads, mlp, B = [int(v) for v in z["meta"]]
+    nreg = int(z["num_register_tokens"]) if "num_register_tokens" in z.files else 0
     enc = DinoVTT(image_size=hw, tactile_size=hw, image_patch_size=p, tactile_patch_size=p, dim=D, depth=depth, heads=heads,
-                  mlp_dim=mlp, num_tactiles=2, num_register_tokens=0)
+                  mlp_dim=mlp, num_tactiles=2, num_register_tokens=nreg)
     enc.load_state_dict({k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
     enc = enc.to(DEV).eval()
     x = {k[len("input/"):]: torch.tensor(z[k]).to(DEV) for k in z.files if k.startswith("input/")}
@@ -253,6 +257,9 @@ def test_dino_style_vtt_matches_reference_fixture(golden_dir):
     assert set(full.keys()) == {"x_norm_regtokens", "x_norm_patchtokens", "x_prenorm", "masks"}
     np.testing.assert_allclose(full["x_prenorm"].cpu().numpy(), z["full/x_prenorm"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(full["x_norm_patchtokens"].cpu().numpy(), z["full/x_norm_patchtokens"], rtol=1e-3, atol=1e-4)
+    if nreg:
+        assert full["x_norm_regtokens"].shape[1] == nreg
+        np.testing.assert_allclose(full["x_norm_regtokens"].cpu().numpy(), z["full/x_norm_regtokens"], rtol=1e-3, atol=1e-4)
     assert mk.shape == z["masked/x_norm_patchtokens"].shape
     np.testing.assert_allclose(mk.cpu().numpy(), z["masked/x_norm_patchtokens"], rtol=1e-3, atol=1e-4)
     # gradients flow to every embed / transformer / norm parameter and match the oracle
@@ -861,3 +868,53 @@ def test_fused_attention_block_matches_unfused(D, heads, n_img_hw, B):
             num += float((g1 - g0).double().square().sum())
             den += float(g0.double().square().sum())
         assert (num / den) ** 0.5 <= 2e-2, (mode, (num / den) ** 0.5)
+
+
+def test_gradsync_second_backward_accumulates():
+    """with a GradSync installed the kernels write gradients straight into the flat buffer (overwrite).  A second backward
+    before zero_grad() — the reference's `separate_optimizer=False` update runs mae_loss.backward() and then the policy loss through
+    MAEExtractor -> get_embeddings (ppo_mae.py:249-266) — must ADD to the first, as autograd does without a GradSync."""
+    from m3l_amd.parallel import GradSync
+    torch.manual_seed(5)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2).to(DEV)
+    B = 4
+    x = {"image": torch.rand(B, 3, 32, 32, device=DEV), "tactile1": torch.rand(B, 3, 16, 16, device=DEV),
+         "tactile2": torch.rand(B, 3, 16, 16, device=DEV)}
+    noises = [torch.rand(B, 16, device=DEV) for _ in range(3)]
+
+    def two_backwards():
+        mae(x, mask_noise=noises).backward()
+        mae.get_embeddings(x, eval=False).square().mean().backward()
+
+    two_backwards()                                               # plain autograd accumulation = the reference semantics
+    ref = {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}
+    mae.zero_grad(set_to_none=True)
+    sync = GradSync(mae)
+    sync.zero_grad()
+    two_backwards()
+    sync.finish()
+    for n, p in mae.named_parameters():
+        if n in ref:
+            assert torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-7), n
+    # and a parameter update between forward and backward is refused, as autograd refuses it
+    loss = mae(x, mask_noise=noises)
+    with torch.no_grad():
+        mae.to_pixels.weight.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+
+def test_two_rank_data_parallel_step_on_one_gpu():
+    """N > 1 control flow of the real HIP step (chunked transformer backward, GradSync prefix buckets, FlatAdam): two processes share
+    cuda:0 and exchange gradients over gloo (RCCL refuses two ranks per device).  tools/dp_two_rank_check.py asserts that both ranks
+    hold bit-identical parameters after 3 optimizer steps and that they equal a single-process run on the concatenated batch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "tools", "dp_two_rank_check.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ranks identical: True" in r.stdout, r.stdout[-2000:]

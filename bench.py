@@ -82,15 +82,40 @@ def build_model(c, dtype, device):
     return mae.to(device)
 
 
-def cpu_baseline(c, seconds_budget=20.0):
-    """The CPU oracle (plain PyTorch fp32, autograd) on the same architecture: bounded sample, host cores of this box."""
+CFG1 = dict(CFG2, num_tactiles=0)     # BASELINE configs[0]: vision-only MAE, 64x64 RGB, ViT-Tiny, mask 75 %, batch 8 on CPU
+
+
+def _socket_cores():
+    """Physical cores of one socket that this process may use (cgroup / affinity aware)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        cores = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if phys == 0 and core is not None:
+                    cores.add(core)
+                phys = core = None
+        n = len(cores) or allowed
+    except OSError:
+        n = allowed
+    return max(1, min(n, allowed))
+
+
+def _cpu_measure(c, B, threads, warmups, iters, cap_s):
+    """Median samples/s of the CPU oracle (fwd + bwd, fp32) on architecture c at batch B with `threads` torch threads: `warmups` untimed
+    iterations, then up to `iters` timed ones or until `cap_s` seconds have been spent (at least one)."""
     from oracle import vtmae_oracle as O
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     mae = build_model(c, "fp32", "cpu")
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in mae.state_dict().items()}
     cfg = O.OracleCfg(c["image_size"], c["tactile_size"], c["image_patch_size"], c["tactile_patch_size"], c["dim"], c["depth"],
                       c["heads"], c["mlp_dim"], 3, c["num_tactiles"], c["dec_dim"], c["dec_depth"], c["dec_heads"], c["ratio"])
-    B = 64
     g = torch.Generator().manual_seed(1234)
     x = {"image": torch.rand(B, 3, c["image_size"], c["image_size"], generator=g)}
     for i in range(c["num_tactiles"]):
@@ -102,17 +127,47 @@ def cpu_baseline(c, seconds_budget=20.0):
         for p in P.values():
             p.grad = None
         O.vtmae_forward(P, cfg, x, noises)["loss"].backward()
-    step()                                     # warm-up (allocator, thread pool)
-    t0, iters = time.perf_counter(), 0
-    while True:
+    t_all = time.perf_counter()
+    for _ in range(warmups):
         step()
-        iters += 1
-        el = time.perf_counter() - t0
-        if el >= seconds_budget or iters >= 50:
+        if time.perf_counter() - t_all > cap_s:        # a very slow configuration: do not spend the whole cap warming up
             break
-    return {"value": round(B * iters / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"CPU oracle (oracle/vtmae_oracle.py, torch fp32 + autograd), cfg-2 model, B={B}, {iters} fwd+bwd iterations"
-                      f" in {el:.1f} s, {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs"}
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < iters and (not times or time.perf_counter() - t_all < cap_s):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"samples_per_s": round(B / med, 2), "batch": B, "threads": threads, "iters": len(times), "median_s": round(med, 4)}
+
+
+def cpu_baseline():
+    """BASELINE.md section 5 / SURVEY.md 8(d): the CPU oracle (a restatement of the reference's PyTorch path, fixture-verified) on this
+    box's host cores — cfg 1 exactly (vision-only, B = 8) and cfg 2 at B = 64, each with 1 thread and with the physical cores of one
+    socket; 5 warm-ups, median of up to 20 iterations, every measurement capped so that the whole baseline stays within ~35 s."""
+    keep = torch.get_num_threads()
+    sock = _socket_cores()
+    rows = {}
+    try:
+        rows["cfg1_B8_1thread"] = _cpu_measure(CFG1, 8, 1, 5, 20, 5.0)
+        rows["cfg1_B8_socket"] = _cpu_measure(CFG1, 8, sock, 5, 20, 4.0)
+        rows["cfg2_B64_socket"] = _cpu_measure(CFG2, 64, sock, 5, 20, 14.0)
+        rows["cfg2_B8_1thread"] = _cpu_measure(CFG2, 8, 1, 2, 20, 8.0)      # B = 64 on one thread is ~1 minute per iteration: B = 8 stated
+    finally:
+        torch.set_num_threads(keep)
+    main = rows["cfg2_B64_socket"]
+    cpu_model = ""
+    try:
+        cpu_model = next(line.split(":", 1)[1].strip() for line in open("/proc/cpuinfo") if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": main["threads"], "kind": "port",
+            "sample": f"CPU oracle (oracle/vtmae_oracle.py, torch {torch.__version__} fp32 + autograd), cfg-2 model at B=64 on {main['threads']} "
+                      f"threads (physical cores of one socket available to this process; {os.cpu_count()} logical CPUs, {cpu_model}): "
+                      f"median of {main['iters']} fwd+bwd iterations after 5 warm-ups, time-capped",
+            "all": rows}
 
 
 def main():
@@ -124,7 +179,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's default (256 for cfg2)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-kernel", default="gemm_nt_glds64", help="kernel class event-timed inside the timed region ('' = every tracked class, diagnostic)")
+    ap.add_argument("--roofline-kernel", default="wgrad[", help="kernel class event-timed inside the timed region ('' = every tracked class, diagnostic)")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: time fwd+bwd without the Adam update")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the result: anything else a library prints there (RCCL's version banner goes to stdout)
@@ -230,11 +285,12 @@ def main():
            "loss": round(float(loss.detach()), 5)}
     if rank == 0:
         import ctypes as C
-        # ---- roofline of the dominant kernel (HIP events recorded by the library around its launches, inside the timed
-        # region, on the launch stream).  The dominant kernel of this step is the LDS-DMA MFMA GEMM instantiation
-        # gemm_nt_glds_kernel<bf16,64,2,*> (every Linear forward and dgrad): skinny K (192..768) makes it HBM-bound
-        # (38..150 FLOP/byte < 2500 TFLOP/s / 8 TB/s = 312 FLOP/byte), so it is priced against the HBM roof; the MFMA
-        # rate it reaches is reported beside it.
+        # ---- roofline of the dominant kernel (HIP events recorded by the library around its launches, inside the timed region, on
+        # the stream the kernel is launched on — the library's side stream for the weight gradients).  By rocprofv3
+        # (profiles/r02_kernel_stats.csv) the single largest kernel of this step is the grouped weight-gradient GEMM
+        # wgrad_kernel<3> (wgrad.hip): 288 FLOP per algorithmic byte at the decoder shapes, below 2500 TFLOP/s / 8 TB/s = 312, so
+        # it is priced against the HBM roof; the MFMA rate it reaches is reported beside it.  Algorithmic bytes = both operands
+        # once + dW once (the split-M slabs are implementation traffic and show up in `traffic`).
         n = lib.m3l_prof_count()
         rows = []
         for i in range(n):
@@ -248,20 +304,29 @@ def main():
             k = kinds.setdefault(name.split("[")[0], [0.0, 0, 0.0, 0.0])
             k[0] += ms_tot; k[1] += launches; k[2] += work; k[3] += byt
         out["kernel_ms_sampled"] = {k: round(v[0] / args.steps, 4) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1][0])}
+        prof_json = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        prof = json.load(open(prof_json)) if os.path.exists(prof_json) else {}
         if kinds:
             kname, (ms_tot, launches, work, byt) = max(kinds.items(), key=lambda kv: kv[1][0])
             raw_us = ms_tot / launches * 1e3
             avg_s = max(raw_us - ev_overhead_us, 0.1) * 1e-6       # bracket minus the empty-bracket cost = kernel time
             gbs = byt / launches / avg_s / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tf):
-                traffic = json.load(open(tf)).get(kname, {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": {"gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname),
-                               "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                               "traffic": traffic, "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2), "avg_bracket_us_raw": round(raw_us, 2), "event_bracket_overhead_us": round(ev_overhead_us, 2),
-                               "launches_sampled": launches,
+            kfull = {"wgrad": "wgrad_kernel<3>", "gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname)
+            traffic = prof.get(kname, {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": kfull, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(gbs / 8000.0, 4), "traffic": traffic,
+                               "traffic_source": "profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU lease (not re-measured in this run)" if traffic else None,
+                               "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2),
+                               "avg_bracket_us_raw": round(raw_us, 2), "event_bracket_overhead_us": round(ev_overhead_us, 2),
+                               "launches_sampled": launches, "launches_per_step": round(launches * 5 / args.steps, 1),
                                "mfma_tflops": round(work / launches / avg_s / 1e12, 1), "mfma_frac_of_2500": round(work / launches / avg_s / 2.5e15, 4)}
+        # whole-step HBM use: PMC bytes per step of the committed profile over THIS run's step time, and the three largest kernels of
+        # the committed rocprofv3 trace with their own HBM fractions (so that the kernels furthest from the roof are visible)
+        if prof.get("_step"):
+            sb = prof["_step"]["hbm_bytes_per_step"]
+            out["step_hbm"] = {"bytes_per_step": sb, "GBps": round(sb / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(sb / (ms * 1e-3) / 8e12, 4),
+                               "source": "profiles/r02_traffic.json (PMC, builder's lease) / this run's ms_per_step"}
+            out["top_kernels"] = prof["_step"].get("top_kernels")
         total_flops = 3 * fwd_flops_per_sample(c) * value
         out["model_tflops"] = round(total_flops / 1e12, 2)
         # BASELINE north_star: throughput also "as fraction of the attention-GEMM roofline" = QK^T + AV FLOPs (fwd + bwd = 3x fwd,
@@ -269,7 +334,7 @@ def main():
         attn = 3 * attn_gemm_fwd_flops_per_sample(c) * value
         out["attention_gemm"] = {"tflops": round(attn / 1e12, 2), "frac_of_bf16_peak": round(attn / (world * PEAK_BF16_TFLOPS * 1e12), 5)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
-            out["cpu_baseline"] = cpu_baseline(c)
+            out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()

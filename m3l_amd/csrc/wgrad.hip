@@ -331,7 +331,7 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
                   "wgrad: N, K, ldy, ldx must be positive multiples of 8 (N=%d K=%d ldy=%d ldx=%d)", p.N, p.K, p.ldy, p.ldx);
         M3L_CHECK((long)M * p.ldy * 2 < 2147483647L && (long)M * p.ldx * 2 < 2147483647L, "wgrad: operand larger than 2 GiB");
         flops += 2.0 * M * p.N * p.K;
-        bytes += 2.0 * M * (p.N + p.K);
+        bytes += 2.0 * M * (p.N + p.K) + 4.0 * p.N * p.K;          // algorithmic: both operands once, dW once
     }
     const WgPlanHost pl = plan_of(M, probs, count, &grp);
     grp.count = count;
@@ -345,7 +345,7 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
     M3L_CHECK(ws_bytes >= pl.ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
     const int TB = 64 * pl.tbt;
     {
-        ProfScope prof("wgrad", M, pl.tiles_total, pl.S, flops, st, bytes + (double)pl.ws_bytes);
+        ProfScope prof(count >= 3 ? "wgrad" : "wgrad_small", M, pl.tiles_total, pl.S, flops, st, bytes);   // grouped layer launches vs single Linears
         const dim3 g1(8 * pl.tiles_total * cdiv(pl.S, 8));
         const size_t lds = (size_t)WG_NST * WG_STAGE;
         if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);

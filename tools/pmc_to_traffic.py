@@ -60,16 +60,45 @@ if busy and active:
             cyc = sa / na / 8.0
             w.writerow([k[:110], n, int(cyc), round((sb / n) / (cyc * 1024.0), 4)])
 
-classes = {"gemm_nt_glds64": "gemm_nt_glds_kernel", "gemm_tn": "gemm_tn_glds_kernel", "ln_bwd": "ln_bwd_kernel"}
-traffic = {"_total_bytes_all_kernels_5_steps": int(tot * 1024)}
-for cls, sub in classes.items():
+classes = {"wgrad": "wgrad_kernel", "gemm_nt_glds64": "gemm_nt_glds_kernel", "ln_bwd": "ln_bwd_kernel", "mlp_t192_bwd": "mlp_t192_bwd_kernel",
+           "mlp_t192_fwd": "mlp_t192_fwd_kernel"}
+# steps covered by a PMC pass = launches of the once-per-step optimizer kernel
+steps_f = sum(v[0] for k, v in fetch.items() if "adam_flat" in k) or 1
+steps_w = sum(v[0] for k, v in write.items() if "adam_flat" in k) or 1
+step_bytes = int((2 * sum(v[1] for v in fetch.values()) / steps_f + sum(v[1] for v in write.values()) / steps_w) * 1024)
+traffic = {"_step": {"hbm_bytes_per_step": step_bytes, "steps_in_fetch_pass": steps_f, "steps_in_write_pass": steps_w,
+                     "note": "sum over every kernel of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per optimizer step; L2-miss traffic incl. Infinity-Cache hits"}}
+
+
+def per_launch(sub):
     nf = sum(v[0] for k, v in fetch.items() if sub in k)
     sf = sum(v[1] for k, v in fetch.items() if sub in k)
     nw = sum(v[0] for k, v in write.items() if sub in k)
     sw = sum(v[1] for k, v in write.items() if sub in k)
+    return (nf, sf, nw, sw)
+
+
+for cls, sub in classes.items():
+    nf, sf, nw, sw = per_launch(sub)
     if nf and nw:
         traffic[cls] = {"hbm_bytes_per_launch": int((2 * sf / nf + sw / nw) * 1024), "fetch_size_kb": round(sf / nf, 1), "write_size_kb": round(sw / nw, 1),
                         "launches": nf, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 2 "
                                                 "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md, KB -> bytes x1024; L2-miss traffic incl. Infinity-Cache hits"}
+# the three largest kernels of the --kernel-trace --stats pass with their own HBM rates (PMC bytes per launch / average duration)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    ktot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    top = []
+    for r in rows[:3]:
+        name = r["Name"]
+        key = name.split("(")[0].split("<")[0].split("::")[-1].strip()
+        key = next((sub for sub in ("wgrad_reduce_kernel", "wgrad_kernel", "ln_bwd_kernel", "mlp_block_bwd_kernel", "mlp_block_fwd_kernel", "attn_block_bwd_kernel",
+                                    "attn_block_fwd_kernel", "mlp_t192_bwd_kernel", "mlp_t192_fwd_kernel", "gemm_nt_glds_kernel") if sub in name), key)
+        nf, sf, nw, sw = per_launch(key)
+        avg_us = float(r["AverageNs"]) / 1e3
+        b = int((2 * sf / nf + sw / nw) * 1024) if nf and nw else None
+        top.append({"kernel": key, "share_of_kernel_time": round(float(r["TotalDurationNs"]) / ktot, 4), "avg_us": round(avg_us, 1),
+                    "hbm_bytes_per_launch": b, "hbm_frac_of_8TBps": round(b / (avg_us * 1e-6) / 8e12, 4) if b else None})
+    traffic["_step"]["top_kernels"] = top
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
-print(json.dumps({k: (v["hbm_bytes_per_launch"] if isinstance(v, dict) else v) for k, v in traffic.items()}))
+print(json.dumps({k: (v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_step")) if isinstance(v, dict) else v) for k, v in traffic.items()}))

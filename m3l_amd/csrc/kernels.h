@@ -157,6 +157,11 @@ int m3l_mlp_t192_short(void);        // 1: use the row-tiled MLP kernels for sho
 int m3l_mlp_t192_tiles(int M);      // partial rows written to cs_part [tiles][mlp] and ln_part [tiles][3 D]
 int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u, const void* w2T,
                      const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st);
+// dxn1 = dqkv Wqkv + LN1 backward per 192-row tile (long sequences); ln_part [tiles][3 D]
+int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M);
+int m3l_qkv_bwd_t192_tiles(int M);
+int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
+                     float* dx_out, void* dxt_out, float* ln_part, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,
                  int H, hipStream_t st);

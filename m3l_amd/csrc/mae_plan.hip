@@ -718,6 +718,13 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             r.part = w.scratch; r.eps = LN_EPS;
             if (m3l_gemm_nt_rowln(dt, ROWLN_BWD, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &r, st)) return 1;   // dxn1 + LN1 backward
             if (m3l_reduce_rows_seg3(w.scratch, cdiv(M, 64), D, g[0], g[1], db_prev, 0, st)) return 1;
+        } else if (m3l_qkv_bwd_t192_supported(dt, D, 3 * HD, M)) {
+            // long sequences: dxn1 and the LN1 backward per 192-row tile, dxn1 never leaves the registers
+            if (l && claim_set(nxt)) return 2;
+            const int tiles = m3l_qkv_bwd_t192_tiles(M);
+            if (m3l_qkv_bwd_t192(M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
+                                 ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
+                return 1;
         } else {
             e = epi0(D);
             e.out_t = w.dxn;

@@ -292,6 +292,73 @@ __device__ __forceinline__ float col4_sum(float v) {
     return v;
 }
 
+// LayerNorm backward of this wave's 16 token rows, on the registers: dy = yacc (the lane holds columns 16 d + 4 g + r of ITS token),
+// x = the LayerNorm input, G = gamma in LDS.  out = dres + dLN/dx -> dx_out (fp32) and dxt_out (bf16, may be null); the wave's
+// column sums of (dy * xhat | dy | out) -> LP[wave][3 D] at `lp_base` (a region every wave has stopped using: barrier T1 inside;
+// T2 after the partials are written).  active = false: the wave only keeps the two barriers (rows past M, parities > 0).
+// Token sums = 48 registers + 2 shuffles; sums over the 16 tokens of a column = one DPP row reduction.
+__device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[12], const float* __restrict__ x, const float* G,
+                                            const float* __restrict__ dres, float* __restrict__ dx_out, bf16* __restrict__ dxt_out, float eps,
+                                            long trow, bool active, char* lp_base, int wave, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    f32x4 xh[12];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = active ? *reinterpret_cast<const f32x4*>(x + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (xh[d][0] + xh[d][1]) + (xh[d][2] + xh[d][3]);
+    }
+    const float mean = col4_sum(s) * (1.0f / T_D);
+    float q = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = xh[d] - mean;
+        q += (xh[d][0] * xh[d][0] + xh[d][1] * xh[d][1]) + (xh[d][2] * xh[d][2] + xh[d][3] * xh[d][3]);
+    }
+    const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        xh[d] = xh[d] * rstd;
+        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + 16 * d + 4 * g);
+        s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
+        const f32x4 t = gd * xh[d];
+        s2 += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    s1 = col4_sum(s1) * (1.0f / T_D);
+    s2 = col4_sum(s2) * (1.0f / T_D);
+    __builtin_amdgcn_s_barrier();                             // T1: every wave is done with the region LP aliases
+    float* LP = reinterpret_cast<float*>(lp_base) + wave * 3 * T_D;
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        const int col = 16 * d + 4 * g;
+        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
+        f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            rr = (gd - s1 - xh[d] * s2) * rstd + *reinterpret_cast<const f32x4*>(dres + trow * T_D + col);
+            *reinterpret_cast<f32x4*>(dx_out + trow * T_D + col) = rr;
+            if (dxt_out) {
+                bf16x4 pk;
+                pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
+                *reinterpret_cast<bf16x4*>(dxt_out + trow * T_D + col) = pk;
+            }
+        }
+        f32x4 pg = yacc[d] * xh[d], pb = yacc[d], pc = rr;
+        if (!active) { pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pg[e] = row16_sum_t(pg[e]); pb[e] = row16_sum_t(pb[e]); pc[e] = row16_sum_t(pc[e]);
+        }
+        if (li == 0) {
+            *reinterpret_cast<f32x4*>(LP + col) = pg;
+            *reinterpret_cast<f32x4*>(LP + T_D + col) = pb;
+            *reinterpret_cast<f32x4*>(LP + 2 * T_D + col) = pc;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // T2: partials complete
+}
+
 template <int TT, int CP>
 __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
                                                                    const float* __restrict__ x1, const float* __restrict__ ln2_w,
@@ -392,63 +459,8 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kerne
         }
     }
     reduce_to_parity0<TT, CP>(RING, tw, cp, lane, yacc);     // (two barriers when CP > 1)
-    // ---- LN2 backward on the registers: the lane holds columns 16 d + 4 g + r of ITS token; token sums = registers + 2 shuffles.
-    // With CP parities the waves of parity 0 do it for their token tile; the others only keep the barrier count.
-    const bool lnw = (cp == 0);
-    f32x4 xh[12];
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-        xh[d] = (ok && lnw) ? *reinterpret_cast<const f32x4*>(x1 + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        s += (xh[d][0] + xh[d][1]) + (xh[d][2] + xh[d][3]);
-    }
-    const float mean = col4_sum(s) * (1.0f / T_D);
-    float q = 0.f;
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-        xh[d] = xh[d] - mean;
-        q += (xh[d][0] * xh[d][0] + xh[d][1] * xh[d][1]) + (xh[d][2] * xh[d][2] + xh[d][3] * xh[d][3]);
-    }
-    const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + eps);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-        xh[d] = xh[d] * rstd;
-        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + 16 * d + 4 * g);
-        s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
-        const f32x4 t = gd * xh[d];
-        s2 += (t[0] + t[1]) + (t[2] + t[3]);
-    }
-    s1 = col4_sum(s1) * (1.0f / T_D);
-    s2 = col4_sum(s2) * (1.0f / T_D);
-    __builtin_amdgcn_s_barrier();                             // T1: every wave is done with the ring (LP aliases it) and with CS
-    float* LP = reinterpret_cast<float*>(RING) + wave * 3 * T_D;
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-        const int col = 16 * d + 4 * g;
-        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
-        f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok && lnw) {
-            rr = (gd - s1 - xh[d] * s2) * rstd + *reinterpret_cast<const f32x4*>(dx + trow * T_D + col);
-            *reinterpret_cast<f32x4*>(dx + trow * T_D + col) = rr;
-            bf16x4 pk;
-            pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
-            *reinterpret_cast<bf16x4*>(dx1t_out + trow * T_D + col) = pk;
-        }
-        f32x4 pg = yacc[d] * xh[d], pb = yacc[d], pc = rr;    // rows past M hold zeros in all three
-        if (!ok || !lnw) { pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pg[e] = row16_sum_t(pg[e]); pb[e] = row16_sum_t(pb[e]); pc[e] = row16_sum_t(pc[e]);
-        }
-        if (li == 0) {
-            *reinterpret_cast<f32x4*>(LP + col) = pg;
-            *reinterpret_cast<f32x4*>(LP + T_D + col) = pb;
-            *reinterpret_cast<f32x4*>(LP + 2 * T_D + col) = pc;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                             // T2: partials complete
+    // ---- LN2 backward on the registers (parity-0 waves; the others only keep the barrier count): T1, T2 inside
+    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok && cp == 0, RING, wave, lane);
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * T_D; id += 64 * NCW) {
@@ -467,9 +479,91 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kerne
     __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
 }
 
+// =============================================================================================================================
+// Attention half, last step of the backward:   dxn1 = dqkv Wqkv  (k = 3 H 64);   dx = dres + LN1-backward(dxn1; x, gamma1)
+// (+ compute-type copy for the next layer's weight gradients, + [3 D] partials dgamma1 | dbeta1 | colsum dx = fc2 bias gradient of
+// the layer below).  Rows are independent: any M.  Ring stage s: the two F2 blocks (columns 64 s .. and 64 s + 32 ..) of
+// Wqkv^T [D][3 H 64]; the B fragments (the lane's 8 consecutive dqkv columns of its token) come straight from HBM, one stage ahead.
+struct QkvBwdLayout {
+    static constexpr int RING = 0, G = TileCfg<12, 1>::RING;
+    static constexpr size_t TOTAL = (size_t)G + T_D * 4;
+};
+
+__global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void qkv_bwd_t192_kernel(const bf16* __restrict__ dqkv, const float* __restrict__ x,
+                                                                               const float* __restrict__ ln1_w, const bf16* __restrict__ WqkvT,
+                                                                               const float* __restrict__ dres, float eps, int M, int K,
+                                                                               float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+                                                                               float* __restrict__ ln_part) {
+    using Cf = TileCfg<12, 1>;
+    constexpr int NCW = Cf::NCW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem + QkvBwdLayout::RING;
+    float* G = reinterpret_cast<float*>(smem + QkvBwdLayout::G);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const long row0 = (long)blockIdx.x * Cf::ROWS;
+    const int NS = K >> 6;                                    // stages of two 32-wide k blocks (K % 64 == 0)
+
+    if (wave >= NCW) {
+        dma_ring<12, 1>(wave - NCW, NS, RING, [&](int s, char* dst, int p) {
+            if (p < 12) dma_f2_piece(WqkvT, K, 64 * s, p, dst, lane);
+            else dma_f2_piece(WqkvT, K, 64 * s + 32, p - 12, dst + T_BLK, lane);
+        }, 3);
+        return;
+    }
+    const long trow = row0 + 16 * wave + li;
+    const bool ok = trow < M;
+    for (int id = tid; id < T_D; id += 64 * NCW) G[id] = ln1_w[id];
+    f32x4 yacc[12];
+#pragma unroll
+    for (int d = 0; d < 12; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 bn0 = uint4{0u, 0u, 0u, 0u}, bn1 = bn0;             // the token's dqkv columns 64 s + 8 g .. and 64 s + 32 + 8 g .. of the next stage
+    if (ok) {
+        bn0 = *reinterpret_cast<const uint4*>(dqkv + trow * K + 8 * g);
+        bn1 = *reinterpret_cast<const uint4*>(dqkv + trow * K + 32 + 8 * g);
+    }
+    for (int st = 0; st < NS; ++st) {
+        const Frag<bf16> b0 = {__builtin_bit_cast(bf16x8, bn0)}, b1 = {__builtin_bit_cast(bf16x8, bn1)};
+        if (ok && st + 1 < NS) {
+            bn0 = *reinterpret_cast<const uint4*>(dqkv + trow * K + 64 * (st + 1) + 8 * g);
+            bn1 = *reinterpret_cast<const uint4*>(dqkv + trow * K + 64 * (st + 1) + 32 + 8 * g);
+        }
+        __builtin_amdgcn_s_barrier();                         // stage st landed
+        asm volatile("" ::: "memory");
+        const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE;
+        const char* Wb = Wa + T_BLK;
+        Frag<bf16> fa[2], fn[2];
+        fn[0] = frag_f2(Wa, 0, li, g);
+        fn[1] = frag_f2(Wb, 0, li, g);
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+            fa[0] = fn[0]; fa[1] = fn[1];
+            if (d + 1 < 12) {
+                fn[0] = frag_f2(Wa, d + 1, li, g);
+                fn[1] = frag_f2(Wb, d + 1, li, g);
+            }
+            asm volatile("" ::: "memory");
+            yacc[d] = mma16(fa[0], b0, yacc[d]);
+            yacc[d] = mma16(fa[1], b1, yacc[d]);
+        }
+    }
+    ln_bwd_rows(yacc, x, G, dres, dx_out, dxt_out, eps, trow, ok, RING, wave, lane);      // barriers T1, T2
+    {
+        const float* LP0 = reinterpret_cast<const float*>(RING);
+        for (int id = tid; id < 3 * T_D; id += 64 * NCW) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NCW; ++w) a += LP0[w * 3 * T_D + id];
+            ln_part[(long)blockIdx.x * 3 * T_D + id] = a;
+        }
+    }
+    __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
+}
+
 }  // namespace
 
-// g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip)
+// g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip),
+// 4 = the 192-row kernels that are only chosen for large M (>= 200 tiles) at any M (tests)
 static int g_t192 = 0;
 static int t192_state() {
     if (!g_t192) {
@@ -526,6 +620,25 @@ int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1
     T192_DISPATCH(tt, (mlp_t192_bwd_kernel<TT, CP><<<cdiv(M, 16 * TT), TileCfg<TT, CP>::THREADS, MlpBwdLayout<TT, CP>::total(mlp), st>>>(
                            (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t,
                            cs_part, ln_part)));
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M) {
+    return t192_state() > 0 && dtype == 1 && D == T_D && K % 64 == 0 && K >= 64 && (cdiv(M, 192) >= 200 || (g_t192 & 4));   // bit 4: any M (tests)
+}
+int m3l_qkv_bwd_t192_tiles(int M) { return cdiv(M, 192); }
+
+int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
+                     float* dx_out, void* dxt_out, float* ln_part, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)qkv_bwd_t192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QkvBwdLayout::TOTAL));
+        inited = 1;
+    }
+    ProfScope prof("qkv_bwd_t192", M, K, T_D, 2.0 * M * (double)T_D * K, st, (double)M * (K * 2.0 + T_D * 14.0));
+    qkv_bwd_t192_kernel<<<cdiv(M, 192), TileCfg<12, 1>::THREADS, QkvBwdLayout::TOTAL, st>>>((const bf16*)dqkv, x, ln1_w, (const bf16*)wqkvT, dres, eps, M, K,
+                                                                                          dx_out, (bf16*)dxt_out, ln_part);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -153,6 +153,10 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);
 int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st);
+int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M);
+int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
+                               const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,
+                               const float* b2, void* u, void* h, float* xout, hipStream_t st);
 int m3l_mlp_t192_short(void);        // 1: use the row-tiled MLP kernels for short sequences too
 int m3l_mlp_t192_tiles(int M);      // partial rows written to cs_part [tiles][mlp] and ln_part [tiles][3 D]
 int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u, const void* w2T,

@@ -483,6 +483,14 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         if (!block) {
         if (m3l_gemm_nt(dt, L.xn1, D, L.wqkv, D, M, 3 * HD, D, &e, st)) return 1;
         if (m3l_attn_fwd(dt, L.qkv, L.o, L.lse, B, n, c->heads, st)) return 1;
+        if (c->project_out && !fuse && m3l_attn_tail_mlp_t192_supported(dt, D, HD, mlp, M)) {
+            // long sequences: out-proj + residual + LN2 + fc1 + GELU + fc2 + residual in ONE launch per 192-row tile
+            if (m3l_attn_tail_mlp_t192_fwd(M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h,
+                                           L.xout, st))
+                return 1;
+            x = L.xout;
+            continue;
+        }
         if (c->project_out && fuse) {
             RowLnEpi r;
             memset(&r, 0, sizeof(r));

@@ -19,6 +19,7 @@
 // bf16 operands, fp32 accumulation / residual stream / statistics.  D = 192 (3 heads of 64).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.cuh"
 #include "kernels.h"
@@ -48,6 +49,21 @@ constexpr int PFD = 1;                       // fragment prefetch distance of th
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* gl_vp;
+
+// ---- cross-lane sums ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum_t(float v) {   // sum over the 16 lanes of a DPP row, every lane gets the total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+// sum over the 4 lane groups (lanes li, li + 16, li + 32, li + 48): the reduction over a token's columns that sit in other lanes
+__device__ __forceinline__ float col4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 
 // ---- fragment reads -------------------------------------------------------------------------------------------------------
 // F1 swizzle: the 16 rows a fragment touches are {0-3, 8-11, 16-19, 24-27} + 4 t (see frag_f1p), two per 256-byte bank row
@@ -154,12 +170,26 @@ template <int TT, int CP> struct MlpFwdLayout {
     static size_t total(int mlp) { return (size_t)B1 + (size_t)mlp * 4 + T_D * 4; }
 };
 
-template <int TT, int CP>
+// PRO = 1: the attention half's tail runs first, in the same launch (needs CP = 1 and heads * 64 == D):
+//     x1 = x + o Wo^T + bo;   xn2 = LN2(x1)        (vit_pytorch Attention.to_out + residual, FeedForward.net[0])
+// Wo streams through the first 3 ring stages as F1 blocks read with the permuted row order: accumulator tile t of block c then holds
+// output columns 32 c + 8 g + 4 t + r, so after the LayerNorm (token statistics = 48 registers + 2 shuffles) the lane's 8 values of
+// block c ARE the B fragment of k step c of fc1 — xn2 reaches fc1 without leaving the registers (it is still written out once, for
+// the weight-gradient GEMM), and x1 is written for the residual add at the end and for the backward.
+struct ProArgs {
+    const bf16* o; const float* x; const bf16* Wo; const float* bo; const float* ln_w; const float* ln_b; float eps;
+    float* x1_out; bf16* xn2_out;
+};
+constexpr int PRO_STAGES = 3;
+
+template <int TT, int CP, int PRO>
 __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                                    const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                    const bf16* __restrict__ W2, const float* __restrict__ b2, int M, int mlp,
                                                                    bf16* __restrict__ u_out, bf16* __restrict__ h_out,
-                                                                   float* __restrict__ xout) {
+                                                                   float* __restrict__ xout, ProArgs pro) {
+    static_assert(!PRO || CP == 1, "the fused out-proj prologue needs one parity");
+    constexpr int S0 = PRO ? PRO_STAGES : 0;                  // ring stages taken by the prologue
     using Cf = TileCfg<TT, CP>;
     constexpr int NCW = Cf::NCW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,7 +203,13 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
     const int NS = (NC + CP - 1) / CP;                        // ring stages
 
     if (wave >= NCW) {
-        dma_ring<TT, CP>(wave - NCW, NC, RING, [&](int c, char* dst, int p) {
+        dma_ring<TT, CP>(wave - NCW, NC + S0, RING, [&](int c, char* dst, int p) {
+            if (PRO && c < S0) {                                                  // Wo rows 64 c .. 64 c + 63: two F1 blocks
+                if (p < 12) dma_f1_piece(pro.Wo, T_D, 64 * c, p, dst, lane);
+                else dma_f1_piece(pro.Wo, T_D, 64 * c + 32, p - 12, dst + T_BLK, lane);
+                return;
+            }
+            c -= S0;
             if (p < 12) dma_f1_piece(W1, T_D, 32 * c, p, dst, lane);              // W1 rows 32 c .. (hidden units of the chunk)
             else dma_f2_piece(W2, mlp, 32 * c, p - 12, dst + T_BLK, lane);        // W2 columns 32 c ..
         }, CP > 1 ? 2 : 0);
@@ -182,10 +218,70 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
     const int tw = wave % TT, cp = wave / TT;
     const long trow = row0 + 16 * tw + li;                    // this lane's token (column of every accumulator tile)
     const bool ok = trow < M;
-    Frag<bf16> xb[6];
-    load_tok_frags(xn2, trow, ok, g, xb);
     for (int id = tid; id < mlp; id += 64 * NCW) B1[id] = b1[id];                 // shared: the first ring barrier orders them
     for (int id = tid; id < T_D; id += 64 * NCW) B2[id] = b2[id];
+    Frag<bf16> xb[6];
+    if (!PRO) {
+        load_tok_frags(xn2, trow, ok, g, xb);
+    } else {
+        Frag<bf16> ob[6];
+        load_tok_frags(pro.o, trow, ok, g, ob);
+        f32x4 pa[6][2];
+#pragma unroll
+        for (int s0 = 0; s0 < PRO_STAGES; ++s0) {
+            __builtin_amdgcn_s_barrier();                     // Wo stage landed
+            asm volatile("" ::: "memory");
+            const char* Ws = RING + (s0 % Cf::NSTAGE) * Cf::STAGE;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int c = 2 * s0 + bb;
+                pa[c][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pa[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    pa[c][0] = mma16(frag_f1p(Ws + bb * T_BLK, 0, ks, li, g), ob[ks], pa[c][0]);
+                    pa[c][1] = mma16(frag_f1p(Ws + bb * T_BLK, 1, ks, li, g), ob[ks], pa[c][1]);
+                }
+            }
+        }
+        // x1 = x + y + bo on the lane's columns 32 c + 8 g + 4 t + r; LayerNorm over the token (in-lane sums + the 4 lane groups)
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int col = 32 * c + 8 * g + 4 * t;
+                f32x4 v = pa[c][t] + *reinterpret_cast<const f32x4*>(pro.bo + col);
+                if (ok) {
+                    v += *reinterpret_cast<const f32x4*>(pro.x + trow * T_D + col);
+                    *reinterpret_cast<f32x4*>(pro.x1_out + trow * T_D + col) = v;
+                }
+                pa[c][t] = v;
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        const float mean = col4_sum(sum) * (1.0f / T_D);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pa[c][t] = pa[c][t] - mean;
+                q += (pa[c][t][0] * pa[c][t][0] + pa[c][t][1] * pa[c][t][1]) + (pa[c][t][2] * pa[c][t][2] + pa[c][t][3] * pa[c][t][3]);
+            }
+        const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + pro.eps);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int col = 32 * c + 8 * g + 4 * t;
+                const f32x4 r = pa[c][t] * rstd * *reinterpret_cast<const f32x4*>(pro.ln_w + col) + *reinterpret_cast<const f32x4*>(pro.ln_b + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[c].v[4 * t + e] = (bf16)r[e];
+            }
+            if (ok) *reinterpret_cast<bf16x8*>(pro.xn2_out + trow * T_D + 32 * c + 8 * g) = xb[c].v;
+        }
+        x1 = pro.x1_out;                                      // residual operand of the epilogue (written above by this lane's token)
+    }
 
     f32x4 yacc[12];
 #pragma unroll
@@ -196,7 +292,7 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
         asm volatile("" ::: "memory");
         const int c = st * CP + cp;                           // this parity's chunk of the stage
         if (c >= NC) continue;
-        const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE + cp * T_CHUNK;
+        const char* Wa = RING + ((st + S0) % Cf::NSTAGE) * Cf::STAGE + cp * T_CHUNK;
         const char* Wb = Wa + T_BLK;
         // Software-pipelined by hand: 12 steps (6 k steps of fc1, then 6 pairs of output tiles of fc2), the two fragments of step
         // i + PFD are requested before the MFMAs of step i are issued — the LDS pipe serves the next step while the matrix pipe works,
@@ -277,20 +373,6 @@ template <int TT, int CP> struct MlpBwdLayout {
     static constexpr int RING = 0, CS = TileCfg<TT, CP>::RING;
     static size_t total(int mlp) { return (size_t)CS + (size_t)TT * mlp * 4 + T_D * 4; }
 };
-
-__device__ __forceinline__ float row16_sum_t(float v) {   // sum over the 16 lanes of a DPP row, every lane gets the total
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    return v;
-}
-// sum over the 4 lane groups (lanes li, li + 16, li + 32, li + 48): the reduction over a token's columns that sit in other lanes
-__device__ __forceinline__ float col4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 // LayerNorm backward of this wave's 16 token rows, on the registers: dy = yacc (the lane holds columns 16 d + 4 g + r of ITS token),
 // x = the LayerNorm input, G = gamma in LDS.  out = dres + dLN/dx -> dx_out (fp32) and dxt_out (bf16, may be null); the wave's
@@ -595,14 +677,37 @@ int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const voi
                      void* u, void* h, float* xout, hipStream_t st) {
     static int inited = 0;
     if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<12, 1>::total(1024)));
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<3, 2>::total(1024)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<12, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<12, 1>::total(1024)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<3, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<3, 2>::total(1024)));
         inited = 1;
     }
     const int tt = t192_tt(M);
     ProfScope prof("mlp_t192_fwd", M, mlp, tt, 4.0 * M * (double)T_D * mlp, st, (double)M * (T_D * 2.0 + T_D * 8.0 + mlp * 4.0));
-    T192_DISPATCH(tt, (mlp_t192_fwd_kernel<TT, CP><<<cdiv(M, 16 * TT), TileCfg<TT, CP>::THREADS, MlpFwdLayout<TT, CP>::total(mlp), st>>>(
-                           (const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout)));
+    ProArgs none;
+    memset(&none, 0, sizeof(none));
+    T192_DISPATCH(tt, (mlp_t192_fwd_kernel<TT, CP, 0><<<cdiv(M, 16 * TT), TileCfg<TT, CP>::THREADS, MlpFwdLayout<TT, CP>::total(mlp), st>>>(
+                           (const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout, none)));
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same with the attention half's tail in front (x1 = x + o Wo^T + bo, xn2 = LN2(x1)): one launch for three of the per-op path
+int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M) {
+    return m3l_mlp_t192_supported(dtype, D, mlp, M) && HD == T_D && (cdiv(M, 192) >= 200 || (g_t192 & 4));
+}
+int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
+                               const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,
+                               const float* b2, void* u, void* h, float* xout, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_t192_fwd_kernel<12, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MlpFwdLayout<12, 1>::total(1024)));
+        inited = 1;
+    }
+    ProfScope prof("attn_tail_mlp_t192_fwd", M, mlp, 12, 4.0 * M * (double)T_D * mlp + 2.0 * M * (double)T_D * T_D, st,
+                   (double)M * (T_D * 2.0 + T_D * 4.0 + T_D * 4.0 + T_D * 2.0 + T_D * 8.0 + mlp * 4.0));
+    ProArgs pa = {(const bf16*)o, x, (const bf16*)wo, bo, ln2_w, ln2_b, eps, x1, (bf16*)xn2};
+    mlp_t192_fwd_kernel<12, 1, 1><<<cdiv(M, 192), TileCfg<12, 1>::THREADS, MlpFwdLayout<12, 1>::total(mlp), st>>>(
+        nullptr, nullptr, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout, pa);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -61,6 +61,13 @@ int m3l_set_rowln(int enable);
  * the attention backward block; env M3L_ATTN_BLOCK sets the initial mode.  Returns the
  * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
 int m3l_set_attn_block(int mode);
+/* Deferred join of the side stream.  By default every backward entry point returns with all its gradients ordered on the caller's
+ * stream.  With m3l_set_defer_join(1) the weight gradients that are still running on the library's side stream when a backward
+ * entry point returns are NOT joined: they overlap what the caller enqueues next, and the caller calls m3l_side_join(stream) before
+ * anything on `stream` consumes parameter gradients (optimizer step, all-reduce) — and keeps every workspace it passed to a backward
+ * alive until then.  m3l_amd.parallel.GradSync does both when it is not communicating.  Returns the previous setting / 0. */
+int m3l_set_defer_join(int on);
+int m3l_side_join(void* stream);
 /* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token
  * rows per workgroup (t192.hip).  Bit mask: 1 (default) = sequences longer than 48 tokens, 2 = also the MLP halves of short
  * sequences (48-row tiles, two chunk parities; correct, measured equal to the per-sample block kernels); env M3L_T192 sets the

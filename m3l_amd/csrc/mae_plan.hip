@@ -54,6 +54,23 @@ int side_init() {
     for (auto& e : ss.ev) M3L_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
+// Deferred join (m3l_set_defer_join): the weight gradients of the LAST layers of a backward range have nothing left to hide behind
+// inside the range; with the join deferred they overlap whatever the caller enqueues next (the glue / encoder backward, the patch
+// embed backward) and the caller orders them with m3l_side_join before it consumes the gradients (optimizer step / all-reduce).
+// The caller must also keep the workspaces alive until then (the side stream still reads them).
+int g_defer_join = 0;
+thread_local std::vector<hipEvent_t> t_pending;
+thread_local std::vector<hipEvent_t> t_tail_ring;
+thread_local int t_tail_next = 0;
+hipEvent_t tail_event() {
+    if (t_tail_ring.empty()) {
+        t_tail_ring.resize(16);
+        for (auto& e : t_tail_ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+    hipEvent_t e = t_tail_ring[t_tail_next];
+    t_tail_next = (t_tail_next + 1) % (int)t_tail_ring.size();
+    return e;
+}
 hipEvent_t side_event() {
     std::lock_guard<std::mutex> lock(g_side_mu);
     hipEvent_t e = g_side.ev[g_side.next];
@@ -254,7 +271,19 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
 // =================================================================================================================
 extern "C" {
 
-int m3l_version(void) { return 100; }
+int m3l_version(void) { return 200; }
+
+int m3l_set_defer_join(int on) {
+    const int old = g_defer_join;
+    g_defer_join = on ? 1 : 0;
+    return old;
+}
+
+int m3l_side_join(void* stream) {
+    for (hipEvent_t ev : t_pending) M3L_HIP(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+    t_pending.clear();
+    return 0;
+}
 
 int m3l_set_rowln(int enable) {
     const int old = use_rowln() ? 1 : 0;
@@ -744,18 +773,23 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
     }
     // the batched LayerNorm-parameter reduce: after the last ln_bwd of the range, on the side stream behind the weight gradients
+    bool side_work = !launched.empty();
     if (batches[0].count > 0) {
         hipEvent_t ln_ready = side_event();
         M3L_HIP(hipEventRecord(ln_ready, st));
-        M3L_HIP(hipStreamWaitEvent(s2, ln_ready, 0));
+        M3L_HIP(hipStreamWaitEvent(g_side.s, ln_ready, 0));
         for (const ReduceBatch& rb : batches)
-            if (m3l_reduce_rows_batch(&rb, 0, s2)) return 1;
-        hipEvent_t red_done = side_event();
-        M3L_HIP(hipEventRecord(red_done, s2));
-        M3L_HIP(hipStreamWaitEvent(st, red_done, 0));     // also orders every earlier side-stream kernel (the weight gradients)
+            if (m3l_reduce_rows_batch(&rb, 0, g_side.s)) return 1;
+        side_work = true;
     }
-    // join: every weight gradient is complete before anything later on the caller's stream
-    for (hipEvent_t ev : launched) M3L_HIP(hipStreamWaitEvent(st, ev, 0));
+    // join: every gradient of the range is complete before anything later on the caller's stream — now, or (deferred mode) when the
+    // caller asks for it.  The side stream is in order, so one event behind its last kernel covers all of them.
+    if (side_work) {
+        hipEvent_t tail = g_defer_join ? tail_event() : side_event();
+        M3L_HIP(hipEventRecord(tail, g_side.s));
+        if (g_defer_join) t_pending.push_back(tail);
+        else M3L_HIP(hipStreamWaitEvent(st, tail, 0));
+    }
     if (c->depth == 0 && dx_in && layer_hi == 0) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }

@@ -240,24 +240,34 @@ class TransformerFn(torch.autograd.Function):
         grads, direct = _grad_targets(ctx.sink, ctx.params)
         dx = torch.empty_like(x)
         sink = ctx.sink if direct else None
-        chunk = BWD_CHUNK_LAYERS
-        if chunk is None and sink is not None and sink[1] is not None and sink[0]._comm:
-            chunk = sink[0].layers_per_chunk
-        if not chunk or chunk >= cfg.depth:
-            L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
-                                                L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
-            _done(sink)
-        else:
-            tens_a, grads_a = L.ptr_array(tens), L.ptr_array(grads)
-            hi = cfg.depth
-            while hi > 0:
-                lo = max(0, hi - chunk)
-                L.check(L.lib().m3l_transformer_bwd_range(C.byref(cfg), B, n, L.ptr(x), tens_a, L.ptr(ws), L.ptr(dy), code, L.ptr(dx),
-                                                          grads_a, hi, lo, _stream()), "m3l_transformer_bwd_range")
-                if sink is not None and sink[1] is not None:
-                    done = list(ctx.params[11 * lo:11 * hi]) + (list(ctx.params[11 * cfg.depth:]) if hi == cfg.depth else [])
-                    sink[0].range_done(sink[1], done, last=(lo == 0))
-                hi = lo
+        # direct mode without communication: the weight gradients still running on the library's side stream when the call returns
+        # are joined by GradSync.finish(), which also drops the references that keep their operands alive
+        defer = direct and sink[0]._defer
+        if defer:
+            sink[0]._keep.append((ws, grads, dy))
+            L.lib().m3l_set_defer_join(1)
+        try:
+            chunk = BWD_CHUNK_LAYERS
+            if chunk is None and sink is not None and sink[1] is not None and sink[0]._comm:
+                chunk = sink[0].layers_per_chunk
+            if not chunk or chunk >= cfg.depth:
+                L.check(L.lib().m3l_transformer_bwd(C.byref(cfg), B, n, L.ptr(x), L.ptr_array(tens), L.ptr(ws), L.ptr(dy), code,
+                                                    L.ptr(dx), L.ptr_array(grads), _stream()), "m3l_transformer_bwd")
+                _done(sink)
+            else:
+                tens_a, grads_a = L.ptr_array(tens), L.ptr_array(grads)
+                hi = cfg.depth
+                while hi > 0:
+                    lo = max(0, hi - chunk)
+                    L.check(L.lib().m3l_transformer_bwd_range(C.byref(cfg), B, n, L.ptr(x), tens_a, L.ptr(ws), L.ptr(dy), code, L.ptr(dx),
+                                                              grads_a, hi, lo, _stream()), "m3l_transformer_bwd_range")
+                    if sink is not None and sink[1] is not None:
+                        done = list(ctx.params[11 * lo:11 * hi]) + (list(ctx.params[11 * cfg.depth:]) if hi == cfg.depth else [])
+                        sink[0].range_done(sink[1], done, last=(lo == 0))
+                    hi = lo
+        finally:
+            if defer:
+                L.lib().m3l_set_defer_join(0)
         return (None, None, dx) + _returned(sink, grads)
 
 

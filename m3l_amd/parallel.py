@@ -90,6 +90,11 @@ class GradSync:
         self._works = []
         self._reduced = set()
         self._written = set()                                  # id(param) written directly by a backward since zero_grad()
+        # without communication the last weight gradients of every transformer backward stay on the library's side stream past the
+        # end of the backward call (they overlap the modules that follow) and are joined in finish(); the workspaces they read are
+        # kept alive here until then
+        self._defer = not self._comm
+        self._keep = []
         self.params = [p for _, p in named]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
@@ -146,6 +151,10 @@ class GradSync:
                     self.bucket_done(b)
             if self._sent_end < self.flat.numel():
                 self._span_ready(self._sent_end, self.flat.numel(), flush=True)
+        if self._defer:
+            from . import _lib as L
+            L.check(L.lib().m3l_side_join(torch.cuda.current_stream().cuda_stream), "m3l_side_join")
+            self._keep.clear()
         for w in self._works:
             w.wait()
         if self._works and self.world > 1:
@@ -180,6 +189,8 @@ class FlatAdam:
 
     def step(self):
         from . import _lib as L
+        if self.sync._keep:                      # a backward whose side-stream weight gradients have not been joined yet
+            self.sync.finish()
         g = self.param_groups[0]
         if self.capturable:
             L.check(L.lib().m3l_adam_step_dev(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),

@@ -68,6 +68,7 @@ int m3l_set_attn_block(int mode);
  * alive until then.  m3l_amd.parallel.GradSync does both when it is not communicating.  Returns the previous setting / 0. */
 int m3l_set_defer_join(int on);
 int m3l_side_join(void* stream);
+int m3l_side_pending(void);      /* number of un-joined deferred tails (diagnostic / tests) */
 /* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token
  * rows per workgroup (t192.hip).  Bit mask: 1 (default) = sequences longer than 48 tokens, 2 = also the MLP halves of short
  * sequences (48-row tiles, two chunk parities; correct, measured equal to the per-sample block kernels); env M3L_T192 sets the

@@ -58,17 +58,20 @@ int side_init() {
 // inside the range; with the join deferred they overlap whatever the caller enqueues next (the glue / encoder backward, the patch
 // embed backward) and the caller orders them with m3l_side_join before it consumes the gradients (optimizer step / all-reduce).
 // The caller must also keep the workspaces alive until then (the side stream still reads them).
+// (Process-wide and mutex-guarded, NOT thread-local: torch runs backward on an autograd worker thread, the join comes from the thread
+// that called backward().)
 int g_defer_join = 0;
-thread_local std::vector<hipEvent_t> t_pending;
-thread_local std::vector<hipEvent_t> t_tail_ring;
-thread_local int t_tail_next = 0;
+std::vector<hipEvent_t> g_pending;
+std::vector<hipEvent_t> g_tail_ring;
+int g_tail_next = 0;
 hipEvent_t tail_event() {
-    if (t_tail_ring.empty()) {
-        t_tail_ring.resize(16);
-        for (auto& e : t_tail_ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    if (g_tail_ring.empty()) {
+        g_tail_ring.resize(16);
+        for (auto& e : g_tail_ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
-    hipEvent_t e = t_tail_ring[t_tail_next];
-    t_tail_next = (t_tail_next + 1) % (int)t_tail_ring.size();
+    hipEvent_t e = g_tail_ring[g_tail_next];
+    g_tail_next = (g_tail_next + 1) % (int)g_tail_ring.size();
     return e;
 }
 hipEvent_t side_event() {
@@ -280,9 +283,17 @@ int m3l_set_defer_join(int on) {
 }
 
 int m3l_side_join(void* stream) {
-    for (hipEvent_t ev : t_pending) M3L_HIP(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
-    t_pending.clear();
-    return 0;
+    std::vector<hipEvent_t> evs;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        evs.swap(g_pending);
+    }
+    for (hipEvent_t ev : evs) M3L_HIP(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+    return (int)0;
+}
+int m3l_side_pending(void) {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    return (int)g_pending.size();
 }
 
 int m3l_set_rowln(int enable) {
@@ -787,8 +798,12 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     if (side_work) {
         hipEvent_t tail = g_defer_join ? tail_event() : side_event();
         M3L_HIP(hipEventRecord(tail, g_side.s));
-        if (g_defer_join) t_pending.push_back(tail);
-        else M3L_HIP(hipStreamWaitEvent(st, tail, 0));
+        if (g_defer_join) {
+            std::lock_guard<std::mutex> lock(g_side_mu);
+            g_pending.push_back(tail);
+        } else {
+            M3L_HIP(hipStreamWaitEvent(st, tail, 0));
+        }
     }
     if (c->depth == 0 && dx_in && layer_hi == 0) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;

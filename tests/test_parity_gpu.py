@@ -228,7 +228,12 @@ def test_direct_grad_mode_matches_autograd_mode():
     sync = GradSync(mae)
     sync.flat.fill_(float("nan"))          # every slot must be overwritten by its producer
     mae(x, mask_noise=noises).backward()
+    # without communication the tails of the transformer backwards are still un-joined on the side stream (recorded from the autograd
+    # worker thread) and finish(), called from this thread, joins them
+    from m3l_amd import _lib as L_
+    assert L_.lib().m3l_side_pending() > 0 and len(sync._keep) > 0
     sync.finish()
+    assert L_.lib().m3l_side_pending() == 0 and not sync._keep
     assert torch.isfinite(sync.flat).all()
     for n, p in mae.named_parameters():
         if n in ref:

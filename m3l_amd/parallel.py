@@ -90,11 +90,13 @@ class GradSync:
         self._works = []
         self._reduced = set()
         self._written = set()                                  # id(param) written directly by a backward since zero_grad()
-        # without communication the last weight gradients of every transformer backward stay on the library's side stream past the
-        # end of the backward call (they overlap the modules that follow) and are joined in finish(); the workspaces they read are
-        # kept alive here until then
-        self._defer = not self._comm
+        # the last weight gradients of every transformer backward (chunk) stay on the library's side stream past the end of the
+        # backward call — they overlap the modules that follow — and are joined where the gradients are consumed: in front of each
+        # all-reduce (on a helper stream, so that the compute stream never waits for them) and in finish(); the workspaces they read
+        # are kept alive here until finish()
+        self._defer = dev.type == "cuda"
         self._keep = []
+        self._helper = torch.cuda.Stream(device=dev) if (self._comm and dev.type == "cuda") else None
         self.params = [p for _, p in named]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
@@ -122,7 +124,17 @@ class GradSync:
                 if a <= end < b:
                     end, grew = b, True
         if end > self._sent_end and (flush or end - self._sent_end >= self.min_bucket_elems or end == self.flat.numel()):
-            self._works.append(dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self._helper is not None:
+                # the collective must see the compute stream's gradients AND the weight gradients still on the library's side stream:
+                # both are joined onto a helper stream, the all-reduce is issued from there, the compute stream runs on
+                from . import _lib as L
+                self._helper.wait_stream(torch.cuda.current_stream())
+                L.check(L.lib().m3l_side_join(self._helper.cuda_stream), "m3l_side_join")
+                with torch.cuda.stream(self._helper):
+                    work = dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append(work)
             self._sent_end = end
 
     def bucket_done(self, bucket_id: int):

@@ -153,6 +153,10 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);
 int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st);
+// LN1 + QKV + attention per sample for 48 < n <= 192 (the decoder): xn1, qkv, o, lse as the per-op kernels write them
+int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B);
+int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
+                      void* o, float* lse, hipStream_t st);
 int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M);
 int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
                                const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,

@@ -515,14 +515,21 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
                                    L.xn2, st))
                 return 1;
         }
-        if (!block && (!fuse || l == 0)) {
+        const bool attn_t = !block && !fuse && c->project_out && m3l_attn_t192_fwd_supported(dt, D, c->heads, n, B);
+        if (attn_t) {
+            // long sequences: LN1 + QKV + attention of a sample in one launch (the out-proj + LN2 continue in the feed-forward launch)
+            if (m3l_attn_t192_fwd(B, n, x, ln1_w, ln1_b, L.wqkv, LN_EPS, L.xn1, L.qkv, L.o, L.lse, st)) return 1;
+        }
+        if (!block && !attn_t && (!fuse || l == 0)) {
             if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
         }
         GemmEpi e = epi0(3 * HD);
         e.out_t = L.qkv;
         if (!block) {
+        if (!attn_t) {
         if (m3l_gemm_nt(dt, L.xn1, D, L.wqkv, D, M, 3 * HD, D, &e, st)) return 1;
         if (m3l_attn_fwd(dt, L.qkv, L.o, L.lse, B, n, c->heads, st)) return 1;
+        }
         if (c->project_out && !fuse && m3l_attn_tail_mlp_t192_supported(dt, D, HD, mlp, M)) {
             // long sequences: out-proj + residual + LN2 + fc1 + GELU + fc2 + residual in ONE launch per 192-row tile
             if (m3l_attn_tail_mlp_t192_fwd(M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h,

@@ -642,6 +642,176 @@ __global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void qkv_bwd_t192_kernel
     __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
 }
 
+// =============================================================================================================================
+// Attention half, forward, up to the heads' outputs — one workgroup per SAMPLE (n <= 192 tokens, 3 heads of 64):
+//     xn1 = LN1(x);   q | k | v = xn1 Wqkv^T;   o_h = softmax(q_h k_h^T / 8) v_h;   lse
+// (vit_pytorch Attention.forward up to `out`, models/pretrain_models.py:309; the out-proj + residual + LN2 continue in the feed-forward
+// launch, mlp_t192_fwd_kernel<.., PRO = 1>).  Wave w owns tokens 16 w .. 16 w + 15: its LN1 output is the B fragment of the QKV
+// products (registers), Wqkv streams through the ring as F1 blocks read in the permuted row order, so a lane's 8 values of a block are
+// 8 consecutive head dims of its token: one 16-byte piece of qkv for HBM, the Q^T fragment of the score product, or a 16-byte row
+// piece of the K / V images in LDS.  Scores are computed transposed (S^T = K Q^T: a lane owns one query, softmax over the keys is 48
+// registers + 2 shuffles), all 192 keys at once; P^T feeds O^T = V^T P^T as accumulator-operand, V^T by transpose read.
+// LDS: ring 3 x 24 KiB | K [192][160 B] | V [192][160 B]
+struct AttnFwdLayout {
+    static constexpr int NST = 3, RING = 0, KS = NST * T_CHUNK, VS = KS + 192 * 160, TOTAL = VS + 192 * 160;
+};
+
+__global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void attn_t192_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                                                const float* __restrict__ ln_b, const bf16* __restrict__ Wqkv,
+                                                                                float eps, int n, bf16* __restrict__ xn1_out,
+                                                                                bf16* __restrict__ qkv_out, bf16* __restrict__ o_out,
+                                                                                float* __restrict__ lse_out) {
+    constexpr int NCW = 12, H = 3, QKV = 3 * T_D, KROW = 80;       // K / V image rows of 80 bf16 (160 B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem + AttnFwdLayout::RING;
+    bf16* Ks = reinterpret_cast<bf16*>(smem + AttnFwdLayout::KS);
+    bf16* Vs = reinterpret_cast<bf16*>(smem + AttnFwdLayout::VS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x;
+    const long row0 = (long)b * n;
+
+    if (wave >= NCW) {
+        // stage s = (head s / 3, matrix s % 3 of q | k | v): rows (s % 3) * 192 + 64 (s / 3) .. + 63 of Wqkv as two F1 blocks
+        const int dw = wave - NCW;
+        auto stage = [&](int s) {
+            char* dst = RING + (s % AttnFwdLayout::NST) * T_CHUNK;
+            const int r0 = (s % 3) * T_D + 64 * (s / 3);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int p = dw * 6 + j;
+                if (p < 12) dma_f1_piece(Wqkv, T_D, r0, p, dst, lane);
+                else dma_f1_piece(Wqkv, T_D, r0 + 32, p - 12, dst + T_BLK, lane);
+            }
+        };
+        stage(0);
+        stage(1);
+        for (int s = 0; s < 3 * H; ++s) {
+            if (s + 1 < 3 * H) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // stage s landed; compute waves are done with stage s - 1
+            if (s + 2 < 3 * H) stage(s + 2);
+            if (s % 3 == 2) __builtin_amdgcn_s_barrier();     // K / V images of the head complete (matches the compute waves)
+        }
+        return;
+    }
+    const int tok = 16 * wave + li;                           // token of this lane within the sample
+    const bool ok = tok < n;
+    const long trow = row0 + tok;
+    // ---- LN1 on the lane's 48 columns 32 ks + 8 g + j (the B-fragment layout): token sums = registers + the 4 lane groups
+    Frag<bf16> xb[6];
+    {
+        f32x4 v[6][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v[ks][t] = ok ? *reinterpret_cast<const f32x4*>(x + trow * T_D + 32 * ks + 8 * g + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+                sum += (v[ks][t][0] + v[ks][t][1]) + (v[ks][t][2] + v[ks][t][3]);
+            }
+        const float mean = col4_sum(sum) * (1.0f / T_D);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v[ks][t] = v[ks][t] - mean;
+                q += (v[ks][t][0] * v[ks][t][0] + v[ks][t][1] * v[ks][t][1]) + (v[ks][t][2] * v[ks][t][2] + v[ks][t][3] * v[ks][t][3]);
+            }
+        const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + eps);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int col = 32 * ks + 8 * g + 4 * t;
+                const f32x4 r = v[ks][t] * rstd * *reinterpret_cast<const f32x4*>(ln_w + col) + *reinterpret_cast<const f32x4*>(ln_b + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[ks].v[4 * t + e] = ok ? (bf16)r[e] : (bf16)0.f;
+            }
+            if (ok) *reinterpret_cast<bf16x8*>(xn1_out + trow * T_D + 32 * ks + 8 * g) = xb[ks].v;
+        }
+    }
+    for (int h = 0; h < H; ++h) {
+        Frag<bf16> fq[2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            __builtin_amdgcn_s_barrier();                     // stage (h, m) landed
+            asm volatile("" ::: "memory");
+            const char* Ws = RING + ((3 * h + m) % AttnFwdLayout::NST) * T_CHUNK;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    a0 = mma16(frag_f1p(Ws + bb * T_BLK, 0, ks, li, g), xb[ks], a0);
+                    a1 = mma16(frag_f1p(Ws + bb * T_BLK, 1, ks, li, g), xb[ks], a1);
+                }
+                Frag<bf16> f;                                 // head dims 32 bb + 8 g + j of this lane's token
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f.v[e] = (bf16)a0[e]; f.v[4 + e] = (bf16)a1[e]; }
+                if (ok) *reinterpret_cast<bf16x8*>(qkv_out + trow * QKV + m * T_D + 64 * h + 32 * bb + 8 * g) = f.v;
+                if (m == 0) fq[bb] = f;
+                else *reinterpret_cast<bf16x8*>((m == 1 ? Ks : Vs) + tok * KROW + 32 * bb + 8 * g) = f.v;     // rows past n: zeros
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // K / V images of head h complete
+        // ---- S^T[key][query] = K Q^T / 8 over all keys; softmax over the lane's query column
+        f32x4 sc[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag<bf16> fk = load_kc(Ks + (16 * t + li) * KROW + ks * 32 + 8 * g);
+                sc[t] = mma16(fk, fq[ks], sc[t]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (16 * t + 4 * g + r < n) ? sc[t][r] * 0.125f : -INFINITY;
+                sc[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[t][r] - mx);
+                sc[t][r] = p;
+                ps += p;
+            }
+        ps = col4_sum(ps);
+        f32x4 oacc[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const Frag<bf16> fp = acc_to_frag<bf16>(sc[2 * j], sc[2 * j + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) oacc[d] = mma16(load_ks<KMAP_ACC>(Vs, KROW, 32 * j, 16 * d, lane), fp, oacc[d]);
+        }
+        if (ok) {
+            const float inv = 1.0f / ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(oacc[d][e] * inv);
+                *reinterpret_cast<bf16x4*>(o_out + trow * T_D + 64 * h + 16 * d + 4 * g) = pk;
+            }
+            if (g == 0) lse_out[((long)b * H + h) * n + tok] = mx + __logf(ps);
+        }
+    }
+}
+
 }  // namespace
 
 // g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip),
@@ -744,6 +914,24 @@ int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float
     ProfScope prof("qkv_bwd_t192", M, K, T_D, 2.0 * M * (double)T_D * K, st, (double)M * (K * 2.0 + T_D * 14.0));
     qkv_bwd_t192_kernel<<<cdiv(M, 192), TileCfg<12, 1>::THREADS, QkvBwdLayout::TOTAL, st>>>((const bf16*)dqkv, x, ln1_w, (const bf16*)wqkvT, dres, eps, M, K,
                                                                                           dx_out, (bf16*)dxt_out, ln_part);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B) {
+    return t192_state() > 0 && dtype == 1 && D == T_D && heads == 3 && n > 48 && n <= 192 && (B >= 200 || (g_t192 & 4));
+}
+int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
+                      void* o, float* lse, hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_t192_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnFwdLayout::TOTAL));
+        inited = 1;
+    }
+    ProfScope prof("attn_t192_fwd", B, n, T_D, 2.0 * B * n * 3.0 * T_D * T_D + 4.0 * B * 3 * (double)n * n * 64, st,
+                   (double)B * n * (T_D * 4.0 + T_D * 2.0 + 3.0 * T_D * 2.0 + T_D * 2.0));
+    attn_t192_fwd_kernel<<<B, TileCfg<12, 1>::THREADS, AttnFwdLayout::TOTAL, st>>>(x, ln_w, ln_b, (const bf16*)wqkv, eps, n, (bf16*)xn1, (bf16*)qkv,
+                                                                                 (bf16*)o, lse);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -157,6 +157,9 @@ int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const voi
 int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B);
 int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
                       void* o, float* lse, hipStream_t st);
+// dO = dx1_t Wo + the whole attention backward of a sample -> dqkv (same support as the forward)
+int m3l_attn_t192_bwd(int B, int n, const void* dx1t, const void* qkv, const void* o, const float* lse, const void* woT, void* dqkv,
+                      hipStream_t st);
 int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M);
 int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
                                const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,

@@ -741,7 +741,12 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
                 return 1;
         }
         const void* d_o = w.dx1_t[cur];
-        if (!attn_block) {
+        const bool attn_t = !attn_block && !fuse && c->project_out && m3l_attn_t192_fwd_supported(dt, D, c->heads, n, B);
+        if (attn_t) {
+            // long sequences: dO + both attention-backward passes of a sample in one launch
+            if (m3l_attn_t192_bwd(B, n, w.dx1_t[cur], L.qkv, L.o, L.lse, L.woT, w.dqkv[cur], st)) return 1;
+        }
+        if (!attn_block && !attn_t) {
         if (c->project_out) {
             e = epi0(HD);
             e.out_t = w.d_o;

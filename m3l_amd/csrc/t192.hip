@@ -812,6 +812,206 @@ __global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void attn_t192_fwd_kerne
     }
 }
 
+// =============================================================================================================================
+// Attention half, backward through the heads — one workgroup per SAMPLE (n <= 192 tokens, 3 heads of 64):
+//     dO = dx1_t Wo (per head);   D = rowsum(dO * O);   P = exp(Q K^T / 8 - lse);   dV = P^T dO;   dS = P * (dO V^T - D) / 8;
+//     dQ = dS K;   dK = dS^T Q                                                       -> dqkv [B n, 3 * 192]
+// (the backward of vit_pytorch Attention between `to_out` and `to_qkv`; replaces the do-GEMM + the two attention-backward passes).
+// Per head: every wave stages its own 16 tokens — K, V, Q rows (from qkv) and dO rows (computed here: Wo^T rows of the head stream
+// in as two F1 blocks, permuted row order -> 8 consecutive head dims per lane) — into four [192][160 B] LDS images, then runs the
+// query-owner pass (S^T = K Q^T, dP^T = V dO^T, dQ^T = K^T dS^T: a lane owns one query) and the key-owner pass (S = Q K^T, dP = dO V^T,
+// dV^T = dO^T P, dK^T = Q^T dS: a lane owns one key) on them: the same arithmetic, in the same order per output, as attention.hip.
+// LDS: W slot 24 KiB | K | V | Q | dO images 4 x 30 KiB | lse [192] | D [192]
+struct AttnBwdLayout {
+    static constexpr int IMG = 192 * 160;
+    static constexpr int W = 0, KS = T_CHUNK, VS = KS + IMG, QS = VS + IMG, GS = QS + IMG, LS = GS + IMG, DS = LS + 192 * 4, TOTAL = DS + 192 * 4;
+};
+
+__global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void attn_t192_bwd_kernel(const bf16* __restrict__ dx1t, const bf16* __restrict__ qkv,
+                                                                                const bf16* __restrict__ o, const float* __restrict__ lse,
+                                                                                const bf16* __restrict__ WoT, int n, bf16* __restrict__ dqkv) {
+    constexpr int NCW = 12, H = 3, QKV = 3 * T_D, KROW = 80;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* WS = smem + AttnBwdLayout::W;
+    bf16* Ks = reinterpret_cast<bf16*>(smem + AttnBwdLayout::KS);
+    bf16* Vs = reinterpret_cast<bf16*>(smem + AttnBwdLayout::VS);
+    bf16* Qs = reinterpret_cast<bf16*>(smem + AttnBwdLayout::QS);
+    bf16* Gs = reinterpret_cast<bf16*>(smem + AttnBwdLayout::GS);
+    float* Ls = reinterpret_cast<float*>(smem + AttnBwdLayout::LS);
+    float* Ds = reinterpret_cast<float*>(smem + AttnBwdLayout::DS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x;
+    const long row0 = (long)b * n;
+
+    if (wave >= NCW) {
+        // the head's 64 rows of Wo^T [H 64][D] as two F1 blocks into the single W slot: requested once every compute wave is done with
+        // the previous head's blocks (barrier B1 of that head), two barriers before they are needed
+        const int dw = wave - NCW;
+        auto load_w = [&](int h) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int p = dw * 6 + j;
+                if (p < 12) dma_f1_piece(WoT, T_D, 64 * h, p, WS, lane);
+                else dma_f1_piece(WoT, T_D, 64 * h + 32, p - 12, WS + T_BLK, lane);
+            }
+        };
+        load_w(0);
+        for (int h = 0; h < H; ++h) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // B0: W of head h landed (and the images of head h - 1 are free)
+            __builtin_amdgcn_s_barrier();                     // B1: images of head h complete, W slot free
+            if (h + 1 < H) load_w(h + 1);
+            __builtin_amdgcn_s_barrier();                     // B2: both passes of head h done
+        }
+        return;
+    }
+    const int tok = 16 * wave + li;
+    const bool ok = tok < n;
+    const long trow = row0 + tok;
+
+    Frag<bf16> xb[6];
+    load_tok_frags(dx1t, trow, ok, g, xb);
+    for (int h = 0; h < H; ++h) {
+        Frag<bf16> fq[2], fdo[2];
+        float dpart = 0.f;
+        {
+        // this wave's 16 rows of q, k, v, o of the head and the lse: requested before the barrier, in flight behind the dO products
+        uint4 zq[2], zk[2], zv[2], zo[2];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            zq[bb] = uint4{0u, 0u, 0u, 0u}; zk[bb] = zq[bb]; zv[bb] = zq[bb]; zo[bb] = zq[bb];
+            if (ok) {
+                const bf16* r = qkv + trow * QKV + 64 * h + 32 * bb + 8 * g;
+                zq[bb] = *reinterpret_cast<const uint4*>(r);
+                zk[bb] = *reinterpret_cast<const uint4*>(r + T_D);
+                zv[bb] = *reinterpret_cast<const uint4*>(r + 2 * T_D);
+                zo[bb] = *reinterpret_cast<const uint4*>(o + trow * T_D + 64 * h + 32 * bb + 8 * g);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                         // B0
+        asm volatile("" ::: "memory");
+        // ---- stage this wave's 16 tokens: dO (computed), Q, K, V rows; D and lse
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                a0 = mma16(frag_f1p(WS + bb * T_BLK, 0, ks, li, g), xb[ks], a0);
+                a1 = mma16(frag_f1p(WS + bb * T_BLK, 1, ks, li, g), xb[ks], a1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fdo[bb].v[e] = (bf16)a0[e]; fdo[bb].v[4 + e] = (bf16)a1[e]; }    // head dims 32 bb + 8 g + j
+            fq[bb].v = __builtin_bit_cast(bf16x8, zq[bb]);
+            const bf16x8 ov = __builtin_bit_cast(bf16x8, zo[bb]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dpart += (float)fdo[bb].v[j] * (float)ov[j];
+            const int off = tok * KROW + 32 * bb + 8 * g;
+            *reinterpret_cast<uint4*>(Qs + off) = zq[bb];
+            *reinterpret_cast<uint4*>(Ks + off) = zk[bb];
+            *reinterpret_cast<uint4*>(Vs + off) = zv[bb];
+            *reinterpret_cast<bf16x8*>(Gs + off) = fdo[bb].v;
+        }
+        }
+        const float Dq = col4_sum(dpart);
+        const float lq = ok ? lse[((long)b * H + h) * n + tok] : INFINITY;          // rows past n: P = exp(.. - inf) = 0
+        if (g == 0) { Ls[tok] = lq; Ds[tok] = Dq; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // B1: images complete
+        asm volatile("" ::: "memory");
+        // ---- query-owner pass: dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query], 32 keys at a time (P needs no row reduction
+        // here: the softmax statistics come from the forward's lse)
+        {
+            f32x4 dq[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int j = 0; j < 6; ++j) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int k0 = 32 * j + 16 * t;
+                    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sacc;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sacc = mma16(load_kc(Ks + (k0 + li) * KROW + ks * 32 + 8 * g), fq[ks], sacc);
+                        dp = mma16(load_kc(Vs + (k0 + li) * KROW + ks * 32 + 8 * g), fdo[ks], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (k0 + 4 * g + r < n) ? __expf(sacc[r] * 0.125f - lq) : 0.f;
+                        ds[t][r] = p * (dp[r] - Dq) * 0.125f;
+                    }
+                }
+                const Frag<bf16> fds = acc_to_frag<bf16>(ds[0], ds[1]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) dq[d] = mma16(load_ks<KMAP_ACC>(Ks, KROW, 32 * j, 16 * d, lane), fds, dq[d]);
+            }
+            if (ok) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)dq[d][e];
+                    *reinterpret_cast<bf16x4*>(dqkv + trow * QKV + 64 * h + 16 * d + 4 * g) = pk;
+                }
+            }
+        }
+        // ---- key-owner pass: dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+        {
+            Frag<bf16> fk[2], fv[2];                          // this lane's own key / value rows, back from the images
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fk[ks] = load_kc(Ks + tok * KROW + ks * 32 + 8 * g);
+                fv[ks] = load_kc(Vs + tok * KROW + ks * 32 + 8 * g);
+            }
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
+#pragma unroll 2
+            for (int j = 0; j < 6; ++j) {
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q0 = 32 * j + 16 * t;
+                    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sacc;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sacc = mma16(load_kc(Qs + (q0 + li) * KROW + ks * 32 + 8 * g), fk[ks], sacc);
+                        dp = mma16(load_kc(Gs + (q0 + li) * KROW + ks * 32 + 8 * g), fv[ks], dp);
+                    }
+                    const f32x4 lr = *reinterpret_cast<const f32x4*>(Ls + q0 + 4 * g);
+                    const f32x4 dr = *reinterpret_cast<const f32x4*>(Ds + q0 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = ok ? __expf(sacc[r] * 0.125f - lr[r]) : 0.f;
+                        p[t][r] = pv;
+                        ds[t][r] = pv * (dp[r] - dr[r]) * 0.125f;
+                    }
+                }
+                const Frag<bf16> fp = acc_to_frag<bf16>(p[0], p[1]);
+                const Frag<bf16> fds = acc_to_frag<bf16>(ds[0], ds[1]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    dv[d] = mma16(load_ks<KMAP_ACC>(Gs, KROW, 32 * j, 16 * d, lane), fp, dv[d]);
+                    dk[d] = mma16(load_ks<KMAP_ACC>(Qs, KROW, 32 * j, 16 * d, lane), fds, dk[d]);
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bf16x4 pk, pv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pk[e] = (bf16)dk[d][e]; pv[e] = (bf16)dv[d][e]; }
+                    *reinterpret_cast<bf16x4*>(dqkv + trow * QKV + T_D + 64 * h + 16 * d + 4 * g) = pk;
+                    *reinterpret_cast<bf16x4*>(dqkv + trow * QKV + 2 * T_D + 64 * h + 16 * d + 4 * g) = pv;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();                         // B2: every wave is done with the images
+    }
+}
+
 }  // namespace
 
 // g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip),
@@ -919,7 +1119,8 @@ int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float
 }
 
 int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B) {
-    return t192_state() > 0 && dtype == 1 && D == T_D && heads == 3 && n > 48 && n <= 192 && (B >= 200 || (g_t192 & 4));
+    static const int attn_on = getenv("M3L_T192_ATTN") ? atoi(getenv("M3L_T192_ATTN")) : 1;      // 0: per-op attention (A/B measurements)
+    return attn_on > 0 && t192_state() > 0 && dtype == 1 && D == T_D && heads == 3 && n > 48 && n <= 192 && (B >= 200 || (g_t192 & 4));
 }
 int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
                       void* o, float* lse, hipStream_t st) {
@@ -932,6 +1133,21 @@ int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const flo
                    (double)B * n * (T_D * 4.0 + T_D * 2.0 + 3.0 * T_D * 2.0 + T_D * 2.0));
     attn_t192_fwd_kernel<<<B, TileCfg<12, 1>::THREADS, AttnFwdLayout::TOTAL, st>>>(x, ln_w, ln_b, (const bf16*)wqkv, eps, n, (bf16*)xn1, (bf16*)qkv,
                                                                                  (bf16*)o, lse);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_attn_t192_bwd(int B, int n, const void* dx1t, const void* qkv, const void* o, const float* lse, const void* woT, void* dqkv,
+                      hipStream_t st) {
+    static int inited = 0;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_t192_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnBwdLayout::TOTAL));
+        inited = 1;
+    }
+    ProfScope prof("attn_t192_bwd", B, n, T_D, 2.0 * B * n * (double)T_D * T_D + 14.0 * B * 3 * (double)n * n * 64, st,
+                   (double)B * n * (T_D * 2.0 + 3.0 * T_D * 2.0 + T_D * 2.0 + 3.0 * T_D * 2.0));
+    attn_t192_bwd_kernel<<<B, TileCfg<12, 1>::THREADS, AttnBwdLayout::TOTAL, st>>>((const bf16*)dx1t, (const bf16*)qkv, (const bf16*)o, lse,
+                                                                                 (const bf16*)woT, n, (bf16*)dqkv);
     M3L_LAUNCH_CHECK();
     return 0;
 }

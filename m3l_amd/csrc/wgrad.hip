@@ -194,17 +194,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const fl
     constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
     const int f = blockIdx.x * 256 + threadIdx.x;
     const int gt = blockIdx.y;
-    if (gt >= grp.tiles_total) {                     // extra column reductions (bias-gradient partial rows)
+    if (gt >= grp.tiles_total) {
+        // extra column reductions (bias-gradient partial rows [G][width]): 32 columns x 8 row slices per block, 4 independent
+        // accumulators per thread, slices added in a fixed order through LDS.  (One thread per column looping over G = 256 rows was a
+        // 128-deep chain of dependent L2 round trips: it alone set this kernel's duration, ~50 us for 12 us worth of slab traffic.)
+        __shared__ float red[8][33];
         const WgExtra& e = grp.ex[gt - grp.tiles_total];
-        if (f >= e.width) return;
-        float s0 = 0.f, s1 = 0.f;
-        int g = 0;
-        for (; g + 1 < e.G; g += 2) {
-            s0 += e.part[(long)g * e.width + f];
-            s1 += e.part[(long)(g + 1) * e.width + f];
+        const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int j = blockIdx.x * 32 + cl;
+        float acc = 0.f;
+        if (j < e.width) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int g = sl;
+            for (; g + 24 < e.G; g += 32) {
+                s0 += e.part[(long)g * e.width + j];
+                s1 += e.part[(long)(g + 8) * e.width + j];
+                s2 += e.part[(long)(g + 16) * e.width + j];
+                s3 += e.part[(long)(g + 24) * e.width + j];
+            }
+            for (; g < e.G; g += 8) s0 += e.part[(long)g * e.width + j];
+            acc = (s0 + s1) + (s2 + s3);
         }
-        if (g < e.G) s0 += e.part[(long)g * e.width + f];
-        e.out[f] = accumulate ? e.out[f] + (s0 + s1) : (s0 + s1);
+        red[sl][cl] = acc;
+        __syncthreads();
+        if (sl == 0 && j < e.width) {
+            float t = red[0][cl];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t += red[i][cl];
+            e.out[j] = accumulate ? e.out[j] + t : t;
+        }
         return;
     }
     if (f >= 64 * TB) return;
@@ -354,7 +372,7 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
     }
     M3L_LAUNCH_CHECK();
     ProfScope prof2("wgrad_reduce", pl.S, pl.tiles_total, count, 0.0, st, (double)pl.ws_bytes);
-    const dim3 g2(cdiv(std::max(64 * TB, maxw), 256), pl.tiles_total + extra_count);
+    const dim3 g2(std::max(cdiv(64 * TB, 256), cdiv(maxw, 32)), pl.tiles_total + extra_count);
     if (pl.tbt == 2) wgrad_reduce_kernel<2><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
     else if (pl.tbt == 3) wgrad_reduce_kernel<3><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
     else wgrad_reduce_kernel<4><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);

@@ -264,15 +264,52 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, in
 
 // ---------------------------------------------------------------------------------------------------------------
 // weights: fp32 master -> compute-type copy (zero-padded leading dim) + transposed copy (for dgrad as an NT GEMM)
+// One 64x64 tile per workgroup, all matrices of the pack in one launch: coalesced fp32 rows in, coalesced compute-type rows out for both
+// copies (the transposed one through LDS).
 template <typename T>
-__global__ void prep_weights_kernel(WeightPack pack) {
-    const WeightDesc d = pack.d[blockIdx.y];
-    const long total = (long)d.rows * d.cols;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / d.cols), c = (int)(i % d.cols);
-        const float v = d.src[i];
-        if (d.dst) reinterpret_cast<T*>(d.dst)[(long)r * d.ld_dst + c] = from_f32<T>(v);
-        if (d.dstT) reinterpret_cast<T*>(d.dstT)[(long)c * d.ld_dstT + r] = from_f32<T>(v);
+__global__ __launch_bounds__(256) void prep_weights_kernel(WeightPack pack) {
+    __shared__ float tile[64][65];
+    int m = 0;
+    while (m + 1 < pack.count && (int)blockIdx.x >= pack.tile0[m + 1]) ++m;
+    const WeightDesc d = pack.d[m];
+    const int tcols = (d.cols + 63) >> 6;
+    const int t = blockIdx.x - pack.tile0[m];
+    const int r0 = (t / tcols) << 6, c0 = (t % tcols) << 6;
+    const int tid = threadIdx.x, q = tid & 15, p = tid >> 4;
+    T* dst = reinterpret_cast<T*>(d.dst);
+    T* dstT = reinterpret_cast<T*>(d.dstT);
+    const bool vec_in = (d.cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + p + 16 * k, c = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < d.rows) {
+            if (vec_in && c + 3 < d.cols) {
+                const float4 f = *reinterpret_cast<const float4*>(d.src + (long)r * d.cols + c);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < d.cols) v[j] = d.src[(long)r * d.cols + c + j];
+            }
+            if (dst) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < d.cols) dst[(long)r * d.ld_dst + c + j] = from_f32<T>(v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[p + 16 * k][4 * q + j] = v[j];
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + p + 16 * k, r = r0 + 4 * q;
+        if (c >= d.cols) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r + j < d.rows) dstT[(long)c * d.ld_dstT + r + j] = from_f32<T>(tile[4 * q + j][p + 16 * k]);
     }
 }
 
@@ -989,14 +1026,22 @@ int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, f
     return m3l_reduce_rows(part_ws, G, N, N, out, accumulate, st);
 }
 
-int m3l_prep_weights(int dtype, const WeightPack* pack, hipStream_t st) {
-    if (pack->count <= 0) return 0;
-    ProfScope prof("prep_weights", pack->count, dtype, 0, 0.0, st);
-    dim3 grid(64, pack->count);
+int m3l_prep_weights(int dtype, const WeightPack* pack_in, hipStream_t st) {
+    if (pack_in->count <= 0) return 0;
+    M3L_CHECK(pack_in->count <= M3L_WPACK, "prep_weights: %d matrices in one pack (max %d)", pack_in->count, M3L_WPACK);
+    WeightPack pack = *pack_in;
+    int tiles = 0;
+    for (int i = 0; i < pack.count; ++i) {
+        pack.tile0[i] = tiles;
+        tiles += ((pack.d[i].rows + 63) / 64) * ((pack.d[i].cols + 63) / 64);
+    }
+    pack.tile0[pack.count] = tiles;
+    if (tiles == 0) return 0;
+    ProfScope prof("prep_weights", pack.count, dtype, 0, 0.0, st);
     if (dtype == 1)
-        prep_weights_kernel<bf16><<<grid, 256, 0, st>>>(*pack);
+        prep_weights_kernel<bf16><<<tiles, 256, 0, st>>>(pack);
     else
-        prep_weights_kernel<float><<<grid, 256, 0, st>>>(*pack);
+        prep_weights_kernel<float><<<tiles, 256, 0, st>>>(pack);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -41,9 +41,10 @@ struct WeightDesc {
     void* dstT;            // [cols, ld_dstT] transposed compute-type copy (or null)
     int rows, cols, ld_dst, ld_dstT;
 };
-#define M3L_WPACK 8
+#define M3L_WPACK 64
 struct WeightPack {
     WeightDesc d[M3L_WPACK];
+    int tile0[M3L_WPACK + 1];   // filled by m3l_prep_weights: first 64x64 tile of each matrix in the launch's tile list
     int count;
 };
 

@@ -470,31 +470,22 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     TfWs w = tf_layout(c, B, n, ws);
     const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim, dt = c->dtype;
     const float* x = x_in;
-    // compute-type weight copies (+ transposes for the dgrads): layer 0 on the caller's stream, layers 1.. on the side stream
-    // while layer 0 computes (fork after everything already queued on `st`, e.g. the optimizer step; join before layer 1)
-    auto prep_layer = [&](int l, hipStream_t ps) -> int {
-        TfLayer& L = w.L[l];
-        const void* const* t = tensors + 11 * l;
+    // compute-type weight copies (+ transposes for the dgrads) of every layer: one launch per 16 layers, on the caller's stream
+    {
         WeightPack pk;
         memset(&pk, 0, sizeof(pk));
-        pk.d[0] = WeightDesc{(const float*)t[2], L.wqkv, L.wqkvT, 3 * HD, D, D, 3 * HD};
-        pk.d[1] = WeightDesc{(const float*)t[7], L.w1, L.w1T, mlp, D, D, mlp};
-        pk.d[2] = WeightDesc{(const float*)t[9], L.w2, L.w2T, D, mlp, mlp, D};
-        pk.count = 3;
-        if (c->project_out) pk.d[pk.count++] = WeightDesc{(const float*)t[3], L.wo, L.woT, D, HD, HD, D};
-        return m3l_prep_weights(dt, &pk, ps);
-    };
-    hipEvent_t prep_done = nullptr;
-    if (c->depth > 0 && prep_layer(0, st)) return 1;
-    if (c->depth > 1) {
-        if (side_init()) return 2;
-        hipEvent_t fork = side_event();
-        M3L_HIP(hipEventRecord(fork, st));
-        M3L_HIP(hipStreamWaitEvent(g_side.s, fork, 0));
-        for (int l = 1; l < c->depth; ++l)
-            if (prep_layer(l, g_side.s)) return 1;
-        prep_done = side_event();
-        M3L_HIP(hipEventRecord(prep_done, g_side.s));
+        for (int l = 0; l < c->depth; ++l) {
+            TfLayer& L = w.L[l];
+            const void* const* t = tensors + 11 * l;
+            pk.d[pk.count++] = WeightDesc{(const float*)t[2], L.wqkv, L.wqkvT, 3 * HD, D, D, 3 * HD};
+            pk.d[pk.count++] = WeightDesc{(const float*)t[7], L.w1, L.w1T, mlp, D, D, mlp};
+            pk.d[pk.count++] = WeightDesc{(const float*)t[9], L.w2, L.w2T, D, mlp, mlp, D};
+            if (c->project_out) pk.d[pk.count++] = WeightDesc{(const float*)t[3], L.wo, L.woT, D, HD, HD, D};
+            if (pk.count + 4 > M3L_WPACK || l + 1 == c->depth) {
+                if (m3l_prep_weights(dt, &pk, st)) return 1;
+                pk.count = 0;
+            }
+        }
     }
     // LayerNorms fused into the epilogue of the GEMM that produces their input (gemm_rowln.hip) when the row width allows it:
     // out-proj + LN2 of the layer, fc2 + LN1 of the next layer (or the final norm).  Only the very first LN1 is a kernel.
@@ -506,7 +497,6 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         const void* const* t = tensors + 11 * l;
         const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *out_b = (const float*)t[4], *ln2_w = (const float*)t[5],
                     *ln2_b = (const float*)t[6], *fc1_b = (const float*)t[8], *fc2_b = (const float*)t[10];
-        if (l == 1 && prep_done) M3L_HIP(hipStreamWaitEvent(st, prep_done, 0));
 
         const bool block = !fuse && m3l_attn_block_supported(dt, D, c->heads, n, c->project_out);
         if (block) {

@@ -265,6 +265,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0          # host done enqueueing (diagnostic: equal to `el` means the host is the bound)
     barrier()
     el = time.perf_counter() - t0
     lib.m3l_prof_end()
@@ -282,7 +283,7 @@ def main():
            "config": {"workload": workload_name,
                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                       "step": "zero_grad + mask + fwd + bwd + grad all-reduce + Adam" if not args.no_optimizer else "fwd + bwd (diagnostic)"},
-           "loss": round(float(loss.detach()), 5)}
+           "loss": round(float(loss.detach()), 5), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
     if rank == 0:
         import ctypes as C
         # ---- roofline of the dominant kernel (HIP events recorded by the library around its launches, inside the timed region, on

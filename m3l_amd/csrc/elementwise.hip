@@ -144,103 +144,59 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
 }
 
 // out[j] = (accumulate ? out[j] : 0) + sum_g part[g*stride + j],  j < count.
-// 32 columns x 8 row-slices per 256-thread block; each slice sums its rows in a fixed order, then the 8 slices are
-// added in a fixed order through LDS -> bitwise reproducible, and G/8 independent loads per thread instead of G serial.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int G, int stride, int count,
-                                                            float* __restrict__ out, int accumulate) {
-    __shared__ float red[8][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + cl;
-    float s = 0.f;
-    if (j < count) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int g = sl;
-        for (; g + 24 < G; g += 32) {
-            s0 += part[(long)g * stride + j];
-            s1 += part[(long)(g + 8) * stride + j];
-            s2 += part[(long)(g + 16) * stride + j];
-            s3 += part[(long)(g + 24) * stride + j];
-        }
-        for (; g < G; g += 8) s0 += part[(long)g * stride + j];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[sl][cl] = s;
-    __syncthreads();
-    if (sl == 0 && j < count) {
-        float t = red[0][cl];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) t += red[i][cl];
-        out[j] = accumulate ? out[j] + t : t;
-    }
-}
-
-// up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment).
-// 32 columns x 32 row-slices per 1024-thread block, 4 independent accumulators per thread: G = 2048 partial rows cost
-// 16 dependent load rounds instead of 64 (this reduce follows every LayerNorm backward: 34 launches per step).
-struct ReduceSegs { float* out[4]; };
-__global__ __launch_bounds__(1024) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
-                                                                 ReduceSegs segs, int accumulate) {
+// 32 columns x 32 row-slices per 1024-thread block; each slice sums its rows in a fixed order with 8 independent accumulators
+// (G = 512 partial rows cost 2 dependent load rounds), then the 32 slices are added in a fixed order through LDS -> bitwise
+// reproducible.  These reductions follow every partial-sum kernel of the step and are pure latency: the loads in flight per thread
+// set their duration.
+__device__ __forceinline__ void reduce_cols_32x32(const float* __restrict__ p, int G, int stride, int j, bool valid,
+                                                  float* __restrict__ out, int accumulate) {
     __shared__ float red[32][33];
-    float* out = segs.out[blockIdx.y];
-    if (!out) return;                            // uniform per block
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + cl;
-    const float* p = part + (long)blockIdx.y * width;
     float s = 0.f;
-    if (j < width) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int g = sl;
-        for (; g + 96 < G; g += 128) {
-            s0 += p[(long)g * stride + j];
-            s1 += p[(long)(g + 32) * stride + j];
-            s2 += p[(long)(g + 64) * stride + j];
-            s3 += p[(long)(g + 96) * stride + j];
+        for (; g + 224 < G; g += 256) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += p[(long)(g + 32 * u) * stride + j];
         }
-        for (; g < G; g += 32) s0 += p[(long)g * stride + j];
-        s = (s0 + s1) + (s2 + s3);
+        for (; g < G; g += 32) a[0] += p[(long)g * stride + j];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     red[sl][cl] = s;
     __syncthreads();
-    if (sl == 0 && j < width) {
+    if (sl == 0 && valid) {
         float t = red[0][cl];
 #pragma unroll
         for (int i = 1; i < 32; ++i) t += red[i][cl];
         out[j] = accumulate ? out[j] + t : t;
     }
+}
+
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, int G, int stride, int count,
+                                                             float* __restrict__ out, int accumulate) {
+    const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+    reduce_cols_32x32(part, G, stride, j, j < count, out, accumulate);
+}
+
+// up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment)
+struct ReduceSegs { float* out[4]; };
+__global__ __launch_bounds__(1024) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
+                                                                 ReduceSegs segs, int accumulate) {
+    float* out = segs.out[blockIdx.y];
+    if (!out) return;                            // uniform per block
+    const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+    reduce_cols_32x32(part + (long)blockIdx.y * width, G, stride, j, j < width, out, accumulate);
 }
 
 // the same reduction for MANY partial slabs in one launch (blockIdx.z = slab): the dgamma / dbeta / bias-gradient partials of every
 // LayerNorm backward of a transformer stack are reduced once, off the critical path, instead of by one small launch per LayerNorm
 __global__ __launch_bounds__(1024) void reduce_rows_batch_kernel(ReduceBatch b, int accumulate) {
-    __shared__ float red[32][33];
     const ReduceBatchItem it = b.it[blockIdx.z];
     float* out = it.out[blockIdx.y];
     if (!out) return;                            // uniform per block
-    const int width = b.D, stride = 3 * b.D, G = it.G;
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + cl;
-    const float* p = it.part + (long)blockIdx.y * width;
-    float s = 0.f;
-    if (j < width) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int g = sl;
-        for (; g + 96 < G; g += 128) {
-            s0 += p[(long)g * stride + j];
-            s1 += p[(long)(g + 32) * stride + j];
-            s2 += p[(long)(g + 64) * stride + j];
-            s3 += p[(long)(g + 96) * stride + j];
-        }
-        for (; g < G; g += 32) s0 += p[(long)g * stride + j];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[sl][cl] = s;
-    __syncthreads();
-    if (sl == 0 && j < width) {
-        float t = red[0][cl];
-#pragma unroll
-        for (int i = 1; i < 32; ++i) t += red[i][cl];
-        out[j] = accumulate ? out[j] + t : t;
-    }
+    const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+    reduce_cols_32x32(it.part + (long)blockIdx.y * b.D, it.G, 3 * b.D, j, j < b.D, out, accumulate);
 }
 
 // column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, rows strided by grid
@@ -831,32 +787,64 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
         }                                                                           \
         acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
     }
-    // phase 1: every row of this wave's run, by position
+    // phase 1: every row of this wave's run, one contiguous same-modality segment at a time, four rows in flight
     const long total = (long)B * N;
     const long r0 = gw * rows_per_wave, r1 = r0 + rows_per_wave < total ? r0 + rows_per_wave : total;
-    int cur_m = -1;
-    for (long r = r0; r < r1; ++r) {
+    for (long r = r0; r < r1;) {
         const int pos = (int)(r % N);
         const int m = pos < n_img ? 0 : 1 + (pos - n_img) / n_tac;
-        if (m != cur_m) {
-            if (cur_m >= 0) { UNSH_FLUSH(cur_m, 1.f) }
-            cur_m = m;
+        const int pos_end = pos < n_img ? n_img : min(N, n_img + m * n_tac);
+        const long seg_end = min(r1, r - pos + pos_end);
+        for (; r + 4 <= seg_end; r += 4) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int e4 = (lane + 64 * c) * 4;
+                if (e4 < dd) {
+                    const float* g = dY + r * dd + e4;
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(g);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(g + dd);
+                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(g + 2 * dd);
+                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(g + 3 * dd);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[c][q] += (d0[q] + d1[q]) + (d2[q] + d3[q]);
+                }
+            }
         }
-        const float* g = dY + r * dd;
+        for (; r < seg_end; ++r) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int e4 = (lane + 64 * c) * 4;
+                if (e4 < dd) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(dY + r * dd + e4);
+                    acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
+                }
+            }
+        }
+        { UNSH_FLUSH(m, 1.f) }
+    }
+    // phase 2: this wave's share of the visible rows: copy out, and subtract their sum from the mask-token slot (four rows in flight)
+    const long vtotal = (long)B * nvis;
+    const long v0 = gw * vis_per_wave, v1 = v0 + vis_per_wave < vtotal ? v0 + vis_per_wave : vtotal;
+    long v = v0;
+    for (; v + 4 <= v1; v += 4) {
+        const float* g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = dY + ((long)((v + u) / nvis) * N + (int)unmasked[v + u]) * dd;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int e4 = (lane + 64 * c) * 4;
             if (e4 < dd) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(g + e4);
-                acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
+                f32x4 d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = *reinterpret_cast<const f32x4*>(g[u] + e4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dsrc + (v + u) * dd + e4) = d[u];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[c][q] += (d[0][q] + d[1][q]) + (d[2][q] + d[3][q]);
             }
         }
     }
-    if (cur_m >= 0) { UNSH_FLUSH(cur_m, 1.f) }
-    // phase 2: this wave's share of the visible rows: copy out, and subtract their sum from the mask-token slot
-    const long vtotal = (long)B * nvis;
-    const long v0 = gw * vis_per_wave, v1 = v0 + vis_per_wave < vtotal ? v0 + vis_per_wave : vtotal;
-    for (long v = v0; v < v1; ++v) {
+    for (; v < v1; ++v) {
         const int b = (int)(v / nvis);
         const int pos = (int)unmasked[v];
         const float* g = dY + ((long)b * N + pos) * dd;
@@ -958,7 +946,7 @@ int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, 
 }
 
 int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st) {
-    reduce_rows_kernel<<<cdiv(count, 32), 256, 0, st>>>(part, G, stride, count, out, accumulate);
+    reduce_rows_kernel<<<cdiv(count, 32), 1024, 0, st>>>(part, G, stride, count, out, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1103,7 +1091,7 @@ int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac,
     const int G = part_grid(rows);
     tokens_assemble_bwd_kernel<<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, B, D, n_img, n_tac > 0 ? n_tac : 1, k, d_img, d_tac, part_ws);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(PL, 32), 256, 0, st>>>(part_ws, G, PL, PL, dmod, accumulate);
+    reduce_rows_kernel<<<cdiv(PL, 32), 1024, 0, st>>>(part_ws, G, PL, PL, dmod, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1249,9 +1237,15 @@ int m3l_embed_finalize_bwd(int dtype, const float* dtok, int L, const float* E, 
     else
         embed_finalize_bwd_kernel<float><<<G, 256, WPB * PL * sizeof(float), st>>>(dtok, L, E, rows, D, *pg, idx, idx_ld, j0, cnt, gamma, eps, (float*)dE, part_ws, nslot);
     M3L_LAUNCH_CHECK();
-    reduce_rows_kernel<<<cdiv(D, 32), 256, 0, st>>>(part_ws, G, PL, D, dgamma, accumulate);
-    reduce_rows_kernel<<<cdiv(D, 32), 256, 0, st>>>(part_ws + D, G, PL, D, dbeta, accumulate);
-    reduce_rows_kernel<<<cdiv(nslot * D, 32), 256, 0, st>>>(part_ws + 2 * D, G, PL, nslot * D, dmod + (long)mod0 * D, accumulate);
+    if (nslot <= 2) {                                           // dgamma | dbeta | dmod rows: equal-width segments, one launch
+        float* dm = dmod + (long)mod0 * D;
+        ReduceSegs segs = {{dgamma, dbeta, dm, nslot > 1 ? dm + D : nullptr}};
+        reduce_rows_seg_kernel<<<dim3(cdiv(D, 32), 2 + nslot), 1024, 0, st>>>(part_ws, G, PL, D, segs, accumulate);
+    } else {
+        reduce_rows_kernel<<<cdiv(D, 32), 1024, 0, st>>>(part_ws, G, PL, D, dgamma, accumulate);
+        reduce_rows_kernel<<<cdiv(D, 32), 1024, 0, st>>>(part_ws + D, G, PL, D, dbeta, accumulate);
+        reduce_rows_kernel<<<cdiv(nslot * D, 32), 1024, 0, st>>>(part_ws + 2 * D, G, PL, nslot * D, dmod + (long)mod0 * D, accumulate);
+    }
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1290,8 +1284,8 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
         ReduceSegs segs = {{dmask_token, ddmod, nmod > 1 ? ddmod + dd : nullptr, nmod > 2 ? ddmod + 2 * dd : nullptr}};
         reduce_rows_seg_kernel<<<dim3(cdiv(dd, 32), 1 + nmod), 1024, 0, st>>>(part_ws, G, PL, dd, segs, accumulate);
     } else {
-        reduce_rows_kernel<<<cdiv(dd, 32), 256, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
-        reduce_rows_kernel<<<cdiv(nmod * dd, 32), 256, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
+        reduce_rows_kernel<<<cdiv(dd, 32), 1024, 0, st>>>(part_ws, G, PL, dd, dmask_token, accumulate);
+        reduce_rows_kernel<<<cdiv(nmod * dd, 32), 1024, 0, st>>>(part_ws + dd, G, PL, nmod * dd, ddmod, accumulate);
     }
     M3L_LAUNCH_CHECK();
     return 0;

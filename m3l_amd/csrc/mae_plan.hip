@@ -81,6 +81,33 @@ hipEvent_t side_event() {
     return e;
 }
 
+// A section of off-critical-path work of a backward call (small weight-gradient GEMMs, bias column sums).  In deferred-join mode
+// fork(st) orders the library's side stream behind everything queued on `st` and returns it, and end() leaves ONE pending tail event
+// for m3l_side_join; otherwise the work stays on the caller's stream.
+struct SideSection {
+    bool on = false;
+    int fork(hipStream_t st, hipStream_t* s) {
+        *s = st;
+        if (!g_defer_join) return 0;
+        if (side_init()) return 2;
+        hipEvent_t ready = side_event();
+        M3L_HIP(hipEventRecord(ready, st));
+        M3L_HIP(hipStreamWaitEvent(g_side.s, ready, 0));
+        *s = g_side.s;
+        on = true;
+        return 0;
+    }
+    int end() {
+        if (!on) return 0;
+        hipEvent_t tail = tail_event();
+        M3L_HIP(hipEventRecord(tail, g_side.s));
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        g_pending.push_back(tail);
+        on = false;
+        return 0;
+    }
+};
+
 struct Arena {
     char* base;
     size_t off = 0;
@@ -349,6 +376,7 @@ struct EmbGroupWs {
 struct EmbWs {
     EmbGroupWs g[2];
     float* scratch;
+    float* scratch_side;     // partial sums of the weight-gradient work when it runs on the side stream (deferred join)
     size_t scratch_b, total;
 };
 EmbWs emb_layout(const Geo& ge, int D, int dtype, int B, void* ws) {
@@ -369,6 +397,7 @@ EmbWs emb_layout(const Geo& ge, int D, int dtype, int B, void* ws) {
     std::vector<std::pair<int, int>> shapes = {{D, ge.pdp_img}, {D, ge.pdp_tac}};
     w.scratch_b = scratch_bytes(std::max(Mmax, 1), shapes, std::max(D * (2 + M3L_MAX_TACTILES), std::max(ge.pdp_img, ge.pdp_tac)));
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.scratch_side = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.total = a.off + 256;
     return w;
 }
@@ -398,6 +427,7 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
     const float* mod = (const float*)tensors[12];
     const float* pos[2] = {(const float*)tensors[13], (const float*)tensors[14]};
     const int mod0[2] = {0, 1};
+    SideSection side;
     if (!backward) {
         // compute-type weight copies of both groups (zero-padded K) in ONE launch; pad columns must be zero (nothing to clear
         // when there is no padding)
@@ -432,9 +462,12 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
             if (m3l_embed_finalize_bwd(dtype, dtokens, L, w.g[i].E, D, &pgs[i], idx, L, j0[i], cnt[i], B, ln2_w, LN_EPS, w.g[i].dE,
                                        w.scratch, gr[4], gr[5], grads[12], mod0[i], 0, st))
                 return 1;
-            if (m3l_gemm_tn(dtype, w.g[i].dE, D, w.g[i].xn, pdp[i], rows, D, pdp[i], w.scratch, w.scratch_b, gr[2], pd[i], D, pd[i], 0, st))
-                return 1;
-            if (m3l_colsum(dtype, w.g[i].dE, rows, D, D, w.scratch, gr[3], 0, st)) return 1;
+            // projection weight / bias gradients: nothing downstream in this call reads them (side stream in deferred-join mode)
+            hipStream_t s2;
+            if (side.fork(st, &s2)) return 2;
+            float* sc = side.on ? w.scratch_side : w.scratch;
+            if (m3l_gemm_tn(dtype, w.g[i].dE, D, w.g[i].xn, pdp[i], rows, D, pdp[i], sc, w.scratch_b, gr[2], pd[i], D, pd[i], 0, s2)) return 1;
+            if (m3l_colsum(dtype, w.g[i].dE, rows, D, D, sc, gr[3], 0, s2)) return 1;
             GemmEpi e = epi0(pdp[i]);
             e.out_t = w.g[i].dxn;
             if (m3l_gemm_nt(dtype, w.g[i].dE, D, w.g[i].wT, D, rows, pdp[i], D, &e, st)) return 1;
@@ -442,7 +475,7 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
                 return 1;
         }
     }
-    return 0;
+    return side.end();
 }
 }  // namespace
 
@@ -975,6 +1008,7 @@ struct HeadWs {
     HeadGroupWs g[2];
     float* loss_part;
     float* scratch;
+    float* scratch_side;     // as EmbWs::scratch_side
     size_t scratch_b, total;
 };
 HeadWs head_layout(const Geo& ge, int dd, int dtype, int B, int nmask, void* ws) {
@@ -996,6 +1030,7 @@ HeadWs head_layout(const Geo& ge, int dd, int dtype, int B, int nmask, void* ws)
     std::vector<std::pair<int, int>> shapes = {{ge.pdp_img, dd}, {ge.pdp_tac, dd}};
     w.scratch_b = scratch_bytes((int)std::max(rows, (size_t)1), shapes, std::max(dd, std::max(ge.pdp_img, ge.pdp_tac)));
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
+    w.scratch_side = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.total = a.off + 256;
     return w;
 }
@@ -1079,6 +1114,7 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
     const int cnt[2] = {nm_img, nmask - nm_img}, j0[2] = {0, nm_img};
     const int pd[2] = {ge.pd_img, ge.pd_tac}, pdp[2] = {ge.pdp_img, ge.pdp_tac};
     M3L_HIP(hipMemsetAsync(d_dec, 0, (size_t)B * N * dd * esz(dtype), st));
+    SideSection side;
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
@@ -1087,15 +1123,17 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
             if (m3l_scale_by_dev(dtype, w.g[i].dpred, (long)rows * pdp[i], dloss, w.g[i].dpred_s, st)) return 1;
             dpred = w.g[i].dpred_s;
         }
-        if (m3l_gemm_tn(dtype, dpred, pdp[i], w.g[i].dg, dd, rows, pdp[i], dd, w.scratch, w.scratch_b, grads[2 * i], dd, pd[i], dd, 0, st))
-            return 1;
-        if (m3l_colsum(dtype, dpred, rows, pd[i], pdp[i], w.scratch, grads[2 * i + 1], 0, st)) return 1;
+        hipStream_t s2;                                    // head weight / bias gradients: side stream in deferred-join mode
+        if (side.fork(st, &s2)) return 2;
+        float* sc = side.on ? w.scratch_side : w.scratch;
+        if (m3l_gemm_tn(dtype, dpred, pdp[i], w.g[i].dg, dd, rows, pdp[i], dd, sc, w.scratch_b, grads[2 * i], dd, pd[i], dd, 0, s2)) return 1;
+        if (m3l_colsum(dtype, dpred, rows, pd[i], pdp[i], sc, grads[2 * i + 1], 0, s2)) return 1;
         GemmEpi e = epi0(dd);
         e.out_t = w.g[i].ddg;
         if (m3l_gemm_nt(dtype, dpred, pdp[i], w.g[i].wT, pdp[i], rows, dd, pdp[i], &e, st)) return 1;
         if (m3l_scatter_rows(dtype, w.g[i].ddg, N, dd, masked, nmask, j0[i], cnt[i], B, d_dec, st)) return 1;
     }
-    return 0;
+    return side.end();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ Each Function is one module of the reference's hot path (models/pretrain_models.
   UnshuffleFn    enc_to_dec + mask tokens + decoder modality/sincos                              :270-307
   HeadsLossFn    masked gather + to_pixels/to_tactiles + weighted MSE                            :260-262,327-340
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -159,6 +160,21 @@ def _pos_grads(pos_img, pos_tac, dtokens, idx):
 
 
 # -------------------------------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def _deferred_join(sink, direct, *keep):
+    """Direct-gradient mode without communication: the library may leave this call's weight-gradient kernels running on its side stream
+    (m3l_set_defer_join); GradSync.finish() joins them and drops `keep`, the references that hold their operands alive until then."""
+    defer = direct and sink[0]._defer
+    if defer:
+        sink[0]._keep.append(keep)
+        L.lib().m3l_set_defer_join(1)
+    try:
+        yield
+    finally:
+        if defer:
+            L.lib().m3l_set_defer_join(0)
+
+
 class EmbedFn(torch.autograd.Function):
     """inputs: image / tactile tensors (no grad), then the 15 tensors of the embed group (see header)."""
 
@@ -190,9 +206,10 @@ class EmbedFn(torch.autograd.Function):
         used = [image is not None] * 6 + [len(tactiles) > 0] * 6 + [True, False, False]
         grads, direct = _grad_targets(ctx.sink, ctx.params, used)
         sink = ctx.sink if direct else None
-        L.check(L.lib().m3l_embed_bwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image),
-                                      L.ptr_array(tactiles), L.ptr_array(tens), L.ptr(ws), L.ptr(dtokens),
-                                      L.ptr_array(grads), _stream()), "m3l_embed_bwd")
+        with _deferred_join(sink, direct, ws, grads, dtokens):
+            L.check(L.lib().m3l_embed_bwd(C.byref(geom), D, dt, B, L_tok, cnt_img, L.ptr(idx), L.ptr(image),
+                                          L.ptr_array(tactiles), L.ptr_array(tens), L.ptr(ws), L.ptr(dtokens),
+                                          L.ptr_array(grads), _stream()), "m3l_embed_bwd")
         _done(sink)
         out = list(_returned(sink, grads))
         out[13], out[14] = _pos_grads(ctx.params[13], ctx.params[14], dtokens, idx)
@@ -357,9 +374,10 @@ class HeadsLossFn(torch.autograd.Function):
         d_dec = torch.empty(B, N, dd, dtype=ddtype, device=dloss.device)
         grads, direct = _grad_targets(ctx.sink, ctx.params, ctx.used)
         sink = ctx.sink if direct else None
-        L.check(L.lib().m3l_heads_loss_bwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr_array(tens),
-                                           L.ptr(ws), L.ptr(dloss), L.ptr(d_dec), L.ptr_array(grads), _stream()),
-                "m3l_heads_loss_bwd")
+        with _deferred_join(sink, direct, ws, grads, dloss):
+            L.check(L.lib().m3l_heads_loss_bwd(C.byref(geom), dd, dt, B, N, nmask, nm_img, L.ptr(masked), L.ptr_array(tens),
+                                               L.ptr(ws), L.ptr(dloss), L.ptr(d_dec), L.ptr_array(grads), _stream()),
+                    "m3l_heads_loss_bwd")
         _done(sink)
         return (None,) * 9 + (d_dec,) + _returned(sink, grads)
 

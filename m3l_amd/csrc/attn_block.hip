@@ -13,6 +13,7 @@
 // drained by the compiler / by its own stores — see DESIGN.md 4b).  bf16 operands, fp32 accumulation and statistics.
 // Supported: D = 64 KT (KT = 2, 3: LDS), heads = D / 64 (so to_out is a real projection with K = D), n <= 48 (3 row tiles).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.cuh"
@@ -109,13 +110,21 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     }
 
     // ---------------------------------------------------------------------- compute waves
-    // ---- LN1: wave w owns rows 4 w .. 4 w + 3 (row = 4 w + g): the row's 16 lanes hold KT float4 chunks (columns 4 (li + 16 c))
+    // ---- LN1: wave w owns rows 4 w .. 4 w + 3 (row = 4 w + g): the row's 16 lanes hold KT float4 chunks (columns 4 (li + 16 c)).
+    // The same thread finishes the same row chunks at the end (residual + LN2): x stays in registers and bo / gamma2 / beta2 are
+    // requested now, so that the tail has no memory round trip left in it.
+    f32x4 x0[KT], bor[KT], g2r[KT], b2r[KT];
     {
         const int r = 4 * wave + g;
         f32x4 xr[KT];
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
+        for (int c = 0; c < KT; ++c) {
             xr[c] = (r < n) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            x0[c] = xr[c];
+            bor[c] = *reinterpret_cast<const f32x4*>(bo + 4 * (li + 16 * c));
+            g2r[c] = *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c));
+            b2r[c] = *reinterpret_cast<const f32x4*>(ln2_b + 4 * (li + 16 * c));
+        }
         float s1 = 0.f;
 #pragma unroll
         for (int c = 0; c < KT; ++c) s1 += (xr[c][0] + xr[c][1]) + (xr[c][2] + xr[c][3]);
@@ -298,8 +307,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         for (int c = 0; c < KT; ++c) {
             v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                v[c] = *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) + *reinterpret_cast<const f32x4*>(bo + 4 * (li + 16 * c)) +
-                       *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c));
+                v[c] = *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) + bor[c] + x0[c];
                 *reinterpret_cast<f32x4*>(x1_out + (row0 + r) * D + 4 * (li + 16 * c)) = v[c];
             }
             s1 += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         if (ok) {
 #pragma unroll
             for (int c = 0; c < KT; ++c) {
-                const f32x4 y = v[c] * rstd * *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c)) + *reinterpret_cast<const f32x4*>(ln2_b + 4 * (li + 16 * c));
+                const f32x4 y = v[c] * rstd * g2r[c] + b2r[c];
                 bf16x4 pk;
                 pk[0] = (bf16)y[0]; pk[1] = (bf16)y[1]; pk[2] = (bf16)y[2]; pk[3] = (bf16)y[3];
                 *reinterpret_cast<bf16x4*>(xn2_out + (row0 + r) * D + 4 * (li + 16 * c)) = pk;
@@ -466,8 +474,12 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntile = (n + 31) >> 5;
+    // operands of the LayerNorm tail (this thread's x / dres row chunks, gamma1): requested during the LAST head's projection blocks,
+    // once the attention registers are free (the head loop is peeled for that), so that the tail starts without a memory round trip
+    f32x4 xr_t[KT], dr_t[KT], gm_t[KT];
 
-    for (int h = 0; h < H; ++h) {
+    auto head = [&](int h, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         float ls_next = INFINITY;
         if (h + 1 < H) {                                                  // next head's tiles and lse on their way (registers)
             if (lrow < n) {
@@ -656,6 +668,16 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
             *reinterpret_cast<uint4*>(dqkv_out + (row0 + r) * 3 * D + t * D + 64 * h + cc * 8) =
                 *reinterpret_cast<const uint4*>(TDQ + t * Ly::T_BYTES + r * TP + cc * 16);
         }
+        if (LAST) {
+            const int r = 4 * wave + g;
+#pragma unroll
+            for (int c = 0; c < KT; ++c) {
+                const int col = 4 * (li + 16 * c);
+                gm_t[c] = *reinterpret_cast<const f32x4*>(ln1_w + col);
+                xr_t[c] = r < n ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dr_t[c] = r < n ? *reinterpret_cast<const f32x4*>(dres + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         // ---- dxn1 += dq_h Wqkv[q_h cols] + dk_h Wqkv[k_h cols] + dv_h Wqkv[v_h cols]: blocks 4h + 1 .. 4h + 3
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -679,7 +701,9 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    };
+    for (int h = 0; h + 1 < H; ++h) head(h, std::false_type{});
+    head(H - 1, std::true_type{});
     __builtin_amdgcn_s_barrier();                                         // BE1: ring free
     float* Y = reinterpret_cast<float*>(WR);
     constexpr int YLD = Ly::Y_PITCH / 4;
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
-            xh[c] = ok ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[c] = xr_t[c];
             s += (xh[c][0] + xh[c][1]) + (xh[c][2] + xh[c][3]);
         }
         const float mean = row16_sum(s) / D;
@@ -716,7 +740,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
         for (int c = 0; c < KT; ++c) {
             xh[c] = xh[c] * rstd;
             dy[c] = ok ? *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gd[c] = dy[c] * *reinterpret_cast<const f32x4*>(ln1_w + 4 * (li + 16 * c));
+            gd[c] = dy[c] * gm_t[c];
             s1 += (gd[c][0] + gd[c][1]) + (gd[c][2] + gd[c][3]);
             const f32x4 t = gd[c] * xh[c];
             s2 += (t[0] + t[1]) + (t[2] + t[3]);
@@ -728,7 +752,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
             const int col = 4 * (li + 16 * c);
             f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                rr = (gd[c] - s1 - xh[c] * s2) * rstd + *reinterpret_cast<const f32x4*>(dres + (row0 + r) * D + col);
+                rr = (gd[c] - s1 - xh[c] * s2) * rstd + dr_t[c];
                 *reinterpret_cast<f32x4*>(dx_out + (row0 + r) * D + col) = rr;
                 if (dxt_out) {
                     bf16x4 pk;

@@ -16,6 +16,9 @@
 
 namespace {
 
+#ifndef MB_ABL
+#define MB_ABL 0            // diagnostic builds only (tools/t192_ablate.sh): bits switch pieces of the forward kernel off
+#endif
 constexpr int MB_CW = 12;
 constexpr int MB_THREADS = 64 * (MB_CW + 1);
 
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
         // ------------------------------------------------------------------ DMA wave
         const int srow = lane >> 3, spc = lane & 7;
         auto issue = [&](int blk) {
+            if (MB_ABL & 1) return;
             char* dst = WR + (blk % Ly::NSTAGE) * Ly::WBLK;
             const int c = blk >> 1;
             if ((blk & 1) == 0) {                         // W1 rows 64c .. 64c+63, all D columns: KT sub-tiles along k
@@ -127,6 +131,18 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0
 
+    // the epilogue's operands (this thread's residual row chunks, b2) are requested now: loaded at the end they were one more exposed
+    // memory round trip of a kernel that is a chain of dependent steps
+    f32x4 x1r[KT], b2r[KT];
+    {
+        const int r = 4 * wave + g;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const int col = 4 * (li + 16 * c);
+            b2r[c] = *reinterpret_cast<const f32x4*>(b2 + col);
+            x1r[c] = r < n ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const int ct = wave & 3, rt = wave >> 2;
     f32x4 yacc[3];                                                        // output tiles (rt, ct + 4 j), j = 0..2 (D / 64 = KT of them used)
 #pragma unroll
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
                 Frag<bf16> fw, fa;
                 fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
                 fa.v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
-                acc = mma16(fa, fw, acc);
+                if (!(MB_ABL & 4)) acc = mma16(fa, fw, acc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                     // u / h chunk visible; W2 chunk c landed (block 2c + 1)
         // u, h chunk -> global: 128-byte row segments
-        for (int id = tid; id < n * 16; id += 64 * MB_CW) {
+        for (int id = tid; id < n * 16 && !(MB_ABL & 2); id += 64 * MB_CW) {
             const int which = id & 1, rc = id >> 1, r = rc >> 3, cc = rc & 7;
             const uint4 v = *reinterpret_cast<const uint4*>((which ? HS : US) + r * Ly::HC_PITCH + cc * 16);
             *reinterpret_cast<uint4*>((which ? h_out : u_out) + (row0 + r) * mlp + 64 * c + cc * 8) = v;
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
                 for (int ks = 0; ks < 2; ++ks) {
                     Frag<bf16> fw;
                     fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
-                    yacc[j] = mma16(fa[ks], fw, yacc[j]);
+                    if (!(MB_ABL & 4)) yacc[j] = mma16(fa[ks], fw, yacc[j]);
                 }
             }
         }
@@ -202,8 +218,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
 #pragma unroll
             for (int c = 0; c < KT; ++c) {
                 const int col = 4 * (li + 16 * c);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Y + r * YLD + col) + *reinterpret_cast<const f32x4*>(b2 + col) +
-                                *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + col);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Y + r * YLD + col) + b2r[c] + x1r[c];
                 *reinterpret_cast<f32x4*>(xout + (row0 + r) * D + col) = v;
             }
         }
@@ -308,6 +323,18 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0
 
+    // the LayerNorm tail's operands (this thread's x1 / dx row chunks, gamma) are requested now (see the forward)
+    f32x4 x1r[KT], dxr[KT], gmr[KT];
+    {
+        const int r = 4 * wave + g;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const int col = 4 * (li + 16 * c);
+            gmr[c] = *reinterpret_cast<const f32x4*>(ln2_w + col);
+            x1r[c] = r < n ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dxr[c] = r < n ? *reinterpret_cast<const f32x4*>(dx + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const int ct = wave & 3, rt = wave >> 2;
     f32x4 yacc[3];
 #pragma unroll
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
-            xh[c] = ok ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[c] = x1r[c];
             s += (xh[c][0] + xh[c][1]) + (xh[c][2] + xh[c][3]);
         }
         const float mean = row16_sum_mb(s) / D;
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
         for (int c = 0; c < KT; ++c) {
             xh[c] = xh[c] * rstd;
             dy[c] = ok ? *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gd[c] = dy[c] * *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c));
+            gd[c] = dy[c] * gmr[c];
             s1 += (gd[c][0] + gd[c][1]) + (gd[c][2] + gd[c][3]);
             const f32x4 t = gd[c] * xh[c];
             s2 += (t[0] + t[1]) + (t[2] + t[3]);
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
             const int col = 4 * (li + 16 * c);
             f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                rr = (gd[c] - s1 - xh[c] * s2) * rstd + *reinterpret_cast<const f32x4*>(dx + (row0 + r) * D + col);
+                rr = (gd[c] - s1 - xh[c] * s2) * rstd + dxr[c];
                 *reinterpret_cast<f32x4*>(dx + (row0 + r) * D + col) = rr;
                 bf16x4 pk;
                 pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];

@@ -37,6 +37,9 @@ constexpr int T_CHUNK = 2 * T_BLK;           // the two blocks of one 32-wide ch
 // <3, 2>: 48 rows (one encoder sample) when M is small — every workgroup streams ALL the weights (~12 us per 590 KB at the measured
 // ~50 GB/s per CU), so a short tile is weight-stream bound; the second parity halves the number of dependent chunk bodies
 // (~0.55 us each: LDS -> 6 chained MFMA steps -> GELU -> 12 MFMAs) that sit between two stage barriers.
+#ifndef T192_ABL
+#define T192_ABL 0          // diagnostic builds only (tools/t192_ablate.sh): bits switch pieces of the kernels off
+#endif
 template <int TT, int CP> struct TileCfg {
     static constexpr int NCW = TT * CP, THREADS = 64 * (NCW + T_DW), ROWS = 16 * TT;
     static constexpr int STAGE = CP * T_CHUNK, NSTAGE = CP == 1 ? 4 : 3, RING = NSTAGE * STAGE;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
                 return;
             }
             c -= S0;
+            if (T192_ABL & 16) return;
             if (p < 12) dma_f1_piece(W1, T_D, 32 * c, p, dst, lane);              // W1 rows 32 c .. (hidden units of the chunk)
             else dma_f2_piece(W2, mlp, 32 * c, p - 12, dst + T_BLK, lane);        // W2 columns 32 c ..
         }, CP > 1 ? 2 : 0);
@@ -318,8 +322,10 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
             asm volatile("" ::: "memory");
             req(ks + PFD, fr[ks % PFD]);
             asm volatile("" ::: "memory");
+            if (!(T192_ABL & 4)) {
             ua[0] = mma16(a0, xb[ks], ua[0]);
             ua[1] = mma16(a1, xb[ks], ua[1]);
+            }
         }
         // bias, pre-activation rounded as the backward will read it, GELU.  Register r of tile t is hidden unit 32 c + 8 g + 4 t + r:
         // the lane's 8 values are consecutive -> one 16-byte piece of u and of h per token, and h is already the B fragment of fc2
@@ -333,8 +339,8 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
                 ub.v[4 + r] = (bf16)(ua[1][r] + bias1[r]);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hb.v[j] = (bf16)gelu_fast((float)ub.v[j]);
-            if (ok) {
+            for (int j = 0; j < 8; ++j) hb.v[j] = (T192_ABL & 2) ? ub.v[j] : (bf16)gelu_fast((float)ub.v[j]);
+            if (ok && !(T192_ABL & 1)) {
                 const long o = trow * mlp + 32 * c + 8 * g;
                 *reinterpret_cast<bf16x8*>(u_out + o) = ub.v;
                 *reinterpret_cast<bf16x8*>(h_out + o) = hb.v;
@@ -346,13 +352,15 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_fwd_kerne
             asm volatile("" ::: "memory");
             if (st2 + PFD < 12) req(st2 + PFD, fr[st2 % PFD]);
             asm volatile("" ::: "memory");
+            if (!(T192_ABL & 4)) {
             yacc[2 * (st2 - 6)] = mma16(a0, hb, yacc[2 * (st2 - 6)]);
             yacc[2 * (st2 - 6) + 1] = mma16(a1, hb, yacc[2 * (st2 - 6) + 1]);
+            } else { yacc[2 * (st2 - 6)][0] += (float)hb.v[st2 & 7]; }
         }
     }
     // xout = x1 + y + b2: a lane holds 4 consecutive columns of its token per tile (parity 0 finishes the token tile)
     reduce_to_parity0<TT, CP>(RING, tw, cp, lane, yacc);
-    if (ok && cp == 0) {
+    if (ok && cp == 0 && (!(T192_ABL & 8) || yacc[0][0] == 1234.5f)) {
 #pragma unroll
         for (int d = 0; d < 12; ++d) {
             const int col = 16 * d + 4 * g;
@@ -387,7 +395,7 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[12], const float
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < 12; ++d) {
-        xh[d] = active ? *reinterpret_cast<const f32x4*>(x + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xh[d] = (active && !(T192_ABL & 32)) ? *reinterpret_cast<const f32x4*>(x + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, (float)d};
         s += (xh[d][0] + xh[d][1]) + (xh[d][2] + xh[d][3]);
     }
     const float mean = col4_sum(s) * (1.0f / T_D);
@@ -416,7 +424,8 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[12], const float
         const int col = 16 * d + 4 * g;
         const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
         f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (active) {
+        if (active && (T192_ABL & 32)) rr = (gd - s1 - xh[d] * s2) * rstd;
+        if (active && !(T192_ABL & 32)) {
             rr = (gd - s1 - xh[d] * s2) * rstd + *reinterpret_cast<const f32x4*>(dres + trow * T_D + col);
             *reinterpret_cast<f32x4*>(dx_out + trow * T_D + col) = rr;
             if (dxt_out) {
@@ -487,7 +496,7 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kerne
         const int c = st * CP + cp;                           // this parity's chunk of the stage
         if (c >= NC) continue;
         const Frag<bf16> uc = {__builtin_bit_cast(bf16x8, un)};
-        if (ok && c + CP < NC) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * (c + CP) + 8 * g);
+        if (ok && c + CP < NC && !(T192_ABL & 128)) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * (c + CP) + 8 * g);
         const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE + cp * T_CHUNK;
         const char* Wb = Wa + T_BLK;
         f32x4 ta[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -520,7 +529,7 @@ __global__ __launch_bounds__((TileCfg<TT, CP>::THREADS)) void mlp_t192_bwd_kerne
             const float t = j < 4 ? ta[0][j & 3] : ta[1][j & 3];
             dub.v[j] = (bf16)(t * gelu_grad_fast((float)uc.v[j]));
         }
-        if (ok) *reinterpret_cast<bf16x8*>(du_out + trow * mlp + 32 * c + 8 * g) = dub.v;
+        if (ok && !(T192_ABL & 64)) *reinterpret_cast<bf16x8*>(du_out + trow * mlp + 32 * c + 8 * g) = dub.v;
         {
             float cs[8];
 #pragma unroll

@@ -62,6 +62,7 @@ int side_init() {
 // that called backward().)
 int g_defer_join = 0;
 std::vector<hipEvent_t> g_pending;
+std::map<const void*, std::vector<hipEvent_t>> g_set_done;   // operand-set events of a backward in progress, by workspace (see bwd_range)
 std::vector<hipEvent_t> g_tail_ring;
 int g_tail_next = 0;
 hipEvent_t tail_event() {
@@ -671,7 +672,16 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     // M3L_WGRAD_INLINE=1: weight gradients on the caller's stream (no overlap, no HBM contention with the dgrad chain) — diagnostic
     static const bool wg_inline = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0;
     hipStream_t s2 = wg_inline ? st : g_side.s;
-    std::vector<hipEvent_t> set_done(NS, nullptr);    // completion of the wgrad launch that last read operand set i
+    // completion of the wgrad launch that last read operand set i.  A backward split into several range calls (chunks, for the
+    // overlap with the gradient all-reduce) carries these across the calls: in deferred-join mode the previous call's weight
+    // gradients may still be reading a set when this call reaches it again.
+    std::vector<hipEvent_t> set_done(NS, nullptr);
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        auto it = g_set_done.find(ws);
+        if (layer_hi < c->depth && it != g_set_done.end() && (int)it->second.size() == NS) set_done = it->second;
+        if (it != g_set_done.end()) g_set_done.erase(it);
+    }
     std::vector<hipEvent_t> launched;                 // every wgrad launch of this call (joined at the end)
     std::vector<TnProblem> pend;                      // weight-gradient problems of the layers waiting for the next grouped launch
     std::vector<TnExtra> pend_ex;
@@ -839,6 +849,10 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         } else {
             M3L_HIP(hipStreamWaitEvent(st, tail, 0));
         }
+    }
+    if (layer_lo > 0 && g_defer_join) {                // more ranges of this backward follow: they inherit the set events
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        g_set_done[ws] = set_done;
     }
     if (c->depth == 0 && dx_in && layer_hi == 0) M3L_HIP(hipMemcpyAsync(dx_in, w.dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;

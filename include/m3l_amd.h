@@ -61,6 +61,10 @@ int m3l_set_rowln(int enable);
  * the attention backward block; env M3L_ATTN_BLOCK sets the initial mode.  Returns the
  * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
 int m3l_set_attn_block(int mode);
+/* Profiling hook of the forward attention block (tools/attn_phase_probe.py): dev_buf = device buffer of >= 8 * B uint64 that every later
+ * launch fills, per sample, with the shader-clock stamps [start, LN1 done, QKV done, attention done, out-proj done, end]; NULL (the
+ * default) switches it off. */
+void m3l_set_attn_phase_buffer(void* dev_buf);
 /* Deferred join of the side stream.  By default every backward entry point returns with all its gradients ordered on the caller's
  * stream.  With m3l_set_defer_join(1) the weight gradients that are still running on the library's side stream when a backward
  * entry point returns are NOT joined: they overlap what the caller enqueues next, and the caller calls m3l_side_join(stream) before

@@ -56,10 +56,15 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
     const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
     float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
-    float* __restrict__ x1_out, bf16* __restrict__ xn2_out) {
+    float* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
     using Ly = AbLayout<KT>;
     constexpr int D = Ly::D, H = KT, KSTEPS = 2 * KT;
     constexpr int NB_QKV = 3 * KT, NB = 4 * KT;          // 64-row weight blocks: Wqkv then Wo
+    // profiling hook (m3l_set_attn_phase_buffer, null in production): shader-clock stamps of thread 0 at the phase boundaries
+    // [start, LN1 done, QKV done, attention done, out-proj done, end] -> phase_ts[block][8]
+    auto stamp = [&](int i) {
+        if (phase_ts && threadIdx.x == 0) phase_ts[(long)blockIdx.x * 8 + i] = __builtin_readcyclecounter();
+    };
     constexpr int NDMA = 8 * KT;                          // LDS-DMA instructions per block (1 KiB each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XN = smem;                                      // [48][XN_PITCH]  bf16 xn1, later o
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     const long row0 = (long)b * n;
     const int RT = (n + 15) >> 4;                         // 16-row tiles that hold real rows
 
+    stamp(0);
     if (wave == AB_CW) {
         // ------------------------------------------------------------------ DMA wave
         const int srow = lane >> 3, spc = lane & 7;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     // ---------------------------------------------------------------------- compute waves
     // ---- LN1: wave w owns rows 4 w .. 4 w + 3 (row = 4 w + g): the row's 16 lanes hold KT float4 chunks (columns 4 (li + 16 c)).
     // The same thread finishes the same row chunks at the end (residual + LN2): x stays in registers and bo / gamma2 / beta2 are
-    // requested now, so that the tail has no memory round trip left in it.
+    // requested before the out-projection, so that the tail has no memory round trip left in it.
     f32x4 x0[KT], bor[KT], g2r[KT], b2r[KT];
     {
         const int r = 4 * wave + g;
@@ -121,9 +127,6 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         for (int c = 0; c < KT; ++c) {
             xr[c] = (r < n) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
             x0[c] = xr[c];
-            bor[c] = *reinterpret_cast<const f32x4*>(bo + 4 * (li + 16 * c));
-            g2r[c] = *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c));
-            b2r[c] = *reinterpret_cast<const f32x4*>(ln2_b + 4 * (li + 16 * c));
         }
         float s1 = 0.f;
 #pragma unroll
@@ -149,27 +152,39 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0: xn1 in LDS
+    stamp(1);
 
     // ---- a 64-column block of A[48 x D] (LDS, row pitch PITCH) times W block^T: wave (ct, rt) owns one 16 x 16 tile
+    // The A fragments (this wave's 16 rows, all k) are the same for every weight block of a projection: read once (load_a).  Per block
+    // the KSTEPS weight fragments are requested together and feed two accumulator chains — one ds_read + MFMA pair after the other on
+    // a single accumulator left the LDS latency and the MFMA dependency exposed KSTEPS times per block (22 % MFMA rate in this phase).
     const int ct = wave & 3, rt = wave >> 2;
-    auto block_mma = [&](const char* Abase, int pitch, const char* Wb) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int wrow = 16 * ct + li;
+    Frag<bf16> fa_c[KSTEPS];
+    auto load_a = [&](const char* Abase, int pitch) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            Frag<bf16> fw, fa;
-            fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
-            fa.v = *reinterpret_cast<const bf16x8*>(Abase + (16 * rt + li) * pitch + (ks * 32 + 8 * g) * 2);
-            acc = mma16(fa, fw, acc);
-        }
-        return acc;
+        for (int ks = 0; ks < KSTEPS; ++ks) fa_c[ks].v = *reinterpret_cast<const bf16x8*>(Abase + (16 * rt + li) * pitch + (ks * 32 + 8 * g) * 2);
     };
+    auto block_mma = [&](const char* Wb) {
+        const int wrow = 16 * ct + li;
+        Frag<bf16> fw[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+            fw[ks].v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks += 2) {
+            a0 = mma16(fa_c[ks], fw[ks], a0);
+            a1 = mma16(fa_c[ks + 1], fw[ks + 1], a1);
+        }
+        return a0 + a1;
+    };
+    if (rt < RT) load_a(XN, Ly::XN_PITCH);
 
     // ---- QKV projection: 3 KT blocks; results (C layout: row 4g + r, col li) -> QKV LDS as bf16
     for (int blk = 0; blk < NB_QKV; ++blk) {
         __builtin_amdgcn_s_barrier();                                     // R_blk
         if (rt < RT) {
-            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk % Ly::NSTAGE) * Ly::WBLK);
+            const f32x4 acc = block_mma(WR + (blk % Ly::NSTAGE) * Ly::WBLK);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 *reinterpret_cast<bf16*>(QKV + (16 * rt + 4 * g + r) * Ly::QKV_PITCH + (64 * blk + 16 * ct + li) * 2) = (bf16)acc[r];
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B1: q | k | v complete in LDS
+    stamp(2);
 
     // ---- qkv -> global (what the unfused to_qkv GEMM writes): 16-byte row segments, all compute threads
     {
@@ -282,20 +298,29 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B2: o in LDS, qkv no longer needed
+    stamp(3);
 
     // ---- out-projection: KT blocks of Wo; y (f32) -> LDS where qkv was
     float* Y = reinterpret_cast<float*>(QKV);
     constexpr int YLD = Ly::Y_PITCH / 4;
+    if (rt < RT) load_a(XN, Ly::XN_PITCH);                                // o rows of this wave's tile
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {                                        // tail operands: on their way during the out-projection
+        bor[c] = *reinterpret_cast<const f32x4*>(bo + 4 * (li + 16 * c));
+        g2r[c] = *reinterpret_cast<const f32x4*>(ln2_w + 4 * (li + 16 * c));
+        b2r[c] = *reinterpret_cast<const f32x4*>(ln2_b + 4 * (li + 16 * c));
+    }
     for (int blk = NB_QKV; blk < NB; ++blk) {
         __builtin_amdgcn_s_barrier();                                     // R_blk
         if (rt < RT) {
-            const f32x4 acc = block_mma(XN, Ly::XN_PITCH, WR + (blk % Ly::NSTAGE) * Ly::WBLK);
+            const f32x4 acc = block_mma(WR + (blk % Ly::NSTAGE) * Ly::WBLK);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Y[(16 * rt + 4 * g + r) * YLD + 64 * (blk - NB_QKV) + 16 * ct + li] = acc[r];
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B3: y complete in LDS
+    stamp(4);
 
     // ---- x1 = x + y + bo (fp32 residual stream), xn2 = LN2(x1): same row -> 16-lane mapping as LN1
     {
@@ -331,9 +356,11 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
             }
         }
     }
+    stamp(5);
 }
 
 int g_ab_state = 0;   // 0 = unknown, 1 = on, -1 = off
+unsigned long long* g_attn_phase_ts = nullptr;   // profiling hook: device buffer [B][8] of phase stamps, or null
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of the attention half of a short-sequence layer, dgrad chain only (weight gradients stay with the grouped TN GEMM on the
@@ -493,14 +520,19 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
         if (rt < RT) {
             const char* Wb = WR + ((4 * h) % Ly::NSTAGE) * Ly::WBLK;
             const int wrow = 16 * ct + li;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<bf16> fw[KSTEPS], fa[KSTEPS];                            // all fragments requested together, two accumulator chains
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                Frag<bf16> fw, fa;
-                fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
-                fa.v = *reinterpret_cast<const bf16x8*>(A0 + (16 * rt + li) * Ly::A_PITCH + (ks * 32 + 8 * g) * 2);
-                acc = mma16(fa, fw, acc);
+                fw[ks].v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+                fa[ks].v = *reinterpret_cast<const bf16x8*>(A0 + (16 * rt + li) * Ly::A_PITCH + (ks * 32 + 8 * g) * 2);
             }
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks += 2) {
+                acc = mma16(fa[ks], fw[ks], acc);
+                acc1 = mma16(fa[ks + 1], fw[ks + 1], acc1);
+            }
+            acc = acc + acc1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(TDO + (16 * rt + 4 * g + r) * TP + (16 * ct + li) * 2) = (bf16)acc[r];
         }
@@ -688,16 +720,18 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
                 Frag<bf16> fa[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8*>(Ts + (16 * rt + li) * TP + (ks * 32 + 8 * g) * 2);
+                Frag<bf16> fw2[KT][2];
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     const int rw = 16 * (ct + 4 * j) + li;
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        Frag<bf16> fw;
-                        fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
-                        yacc[j] = mma16(fa[ks], fw, yacc[j]);
-                    }
+                    for (int ks = 0; ks < 2; ++ks)
+                        fw2[j][ks].v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
                 }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) yacc[j] = mma16(fa[ks], fw2[j][ks], yacc[j]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -802,6 +836,10 @@ extern "C" int m3l_set_attn_block(int mode) {
     return old;
 }
 
+// Profiling hook (tools/attn_phase_probe.py): a device buffer of at least 8 * B uint64 that every later attention-block forward launch
+// fills with the shader-clock stamps of its phase boundaries; NULL switches it off (the default: the kernel then writes nothing).
+extern "C" void m3l_set_attn_phase_buffer(void* dev_buf) { g_attn_phase_ts = reinterpret_cast<unsigned long long*>(dev_buf); }
+
 // 1 when the fused attention-block kernel takes this problem
 int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out) {
     if (ab_state() < 1) return 0;
@@ -825,7 +863,8 @@ int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, 
     ProfScope prof("attn_block_fwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64, st);
 #define AB_LAUNCH(KT)                                                                                                              \
     attn_block_fwd_kernel<KT><<<B, AB_THREADS, AbLayout<KT>::TOTAL, st>>>(x, ln1_w, ln1_b, (const bf16*)wqkv, (const bf16*)wo, bo, ln2_w, \
-                                                                         ln2_b, eps, n, (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse, x1, (bf16*)xn2)
+                                                                         ln2_b, eps, n, (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse, x1, (bf16*)xn2, \
+                                                                         g_attn_phase_ts)
     M3L_CHECK(D == 128 || D == 192, "attn_block: D=%d unsupported", D);
     if (D == 128) AB_LAUNCH(2);
     else AB_LAUNCH(3);

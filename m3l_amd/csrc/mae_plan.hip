@@ -85,11 +85,16 @@ hipEvent_t side_event() {
 // A section of off-critical-path work of a backward call (small weight-gradient GEMMs, bias column sums).  In deferred-join mode
 // fork(st) orders the library's side stream behind everything queued on `st` and returns it, and end() leaves ONE pending tail event
 // for m3l_side_join; otherwise the work stays on the caller's stream.
+// M3L_WGRAD_INLINE=1: every weight gradient on the caller's stream (no overlap: per-kernel PMC counters attribute cleanly) — diagnostic
+bool wgrad_inline() {
+    static const bool on = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0;
+    return on;
+}
 struct SideSection {
     bool on = false;
     int fork(hipStream_t st, hipStream_t* s) {
         *s = st;
-        if (!g_defer_join) return 0;
+        if (!g_defer_join || wgrad_inline()) return 0;
         if (side_init()) return 2;
         hipEvent_t ready = side_event();
         M3L_HIP(hipEventRecord(ready, st));
@@ -669,8 +674,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     }
     if (side_init()) return 2;
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, mlp) && m3l_gemm_nt_rowln_supported(dt, D, 3 * HD);
-    // M3L_WGRAD_INLINE=1: weight gradients on the caller's stream (no overlap, no HBM contention with the dgrad chain) — diagnostic
-    static const bool wg_inline = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0;
+    const bool wg_inline = wgrad_inline();
     hipStream_t s2 = wg_inline ? st : g_side.s;
     // completion of the wgrad launch that last read operand set i.  A backward split into several range calls (chunks, for the
     // overlap with the gradient all-reduce) carries these across the calls: in deferred-join mode the previous call's weight
@@ -830,7 +834,10 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     }
     // the batched LayerNorm-parameter reduce: after the last ln_bwd of the range, on the side stream behind the weight gradients
     bool side_work = !launched.empty();
-    if (batches[0].count > 0) {
+    if (batches[0].count > 0 && wg_inline) {
+        for (const ReduceBatch& rb : batches)
+            if (m3l_reduce_rows_batch(&rb, 0, st)) return 1;
+    } else if (batches[0].count > 0) {
         hipEvent_t ln_ready = side_event();
         M3L_HIP(hipEventRecord(ln_ready, st));
         M3L_HIP(hipStreamWaitEvent(g_side.s, ln_ready, 0));

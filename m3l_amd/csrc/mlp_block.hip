@@ -144,6 +144,11 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
         }
     }
     const int ct = wave & 3, rt = wave >> 2;
+    // this wave's 16 rows of the A operand (all k) are the same for every hidden chunk: read once; per chunk the weight fragments are
+    // requested together and feed two accumulator chains (see attn_block.hip block_mma)
+    Frag<bf16> fa_c[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) fa_c[ks].v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
     f32x4 yacc[3];                                                        // output tiles (rt, ct + 4 j), j = 0..2 (D / 64 = KT of them used)
 #pragma unroll
     for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -158,14 +163,19 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
         if (rt < RT) {
             const char* Wb = WR + ((2 * c) % Ly::NSTAGE) * Ly::WBLK;
             const int wrow = 16 * ct + li;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<bf16> fw[KSTEPS];
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                Frag<bf16> fw, fa;
-                fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
-                fa.v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
-                if (!(MB_ABL & 4)) acc = mma16(fa, fw, acc);
+            for (int ks = 0; ks < KSTEPS; ++ks)
+                fw[ks].v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(MB_ABL & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks += 2) {
+                    acc = mma16(fa_c[ks], fw[ks], acc);
+                    acc1 = mma16(fa_c[ks + 1], fw[ks + 1], acc1);
+                }
             }
+            acc = acc + acc1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bf16 ub = (bf16)(acc[r] + bias);                    // pre-activation as the backward will read it
@@ -188,15 +198,19 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
             Frag<bf16> fa[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8*>(HS + (16 * rt + li) * Ly::HC_PITCH + (ks * 32 + 8 * g) * 2);
+            Frag<bf16> fw2[KT][2];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 const int rw = 16 * (ct + 4 * j) + li;                    // output column (= W2 row) of this lane's B fragment
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    Frag<bf16> fw;
-                    fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
-                    if (!(MB_ABL & 4)) yacc[j] = mma16(fa[ks], fw, yacc[j]);
-                }
+                for (int ks = 0; ks < 2; ++ks)
+                    fw2[j][ks].v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
+            }
+            if (!(MB_ABL & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) yacc[j] = mma16(fa[ks], fw2[j][ks], yacc[j]);
             }
         }
     }
@@ -336,6 +350,11 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
         }
     }
     const int ct = wave & 3, rt = wave >> 2;
+    // this wave's 16 rows of the A operand (all k) are the same for every hidden chunk: read once; per chunk the weight fragments are
+    // requested together and feed two accumulator chains (see attn_block.hip block_mma)
+    Frag<bf16> fa_c[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) fa_c[ks].v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
     f32x4 yacc[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -348,14 +367,17 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
         if (rt < RT) {
             const char* Wb = WR + ((2 * c) % Ly::NSTAGE) * Ly::WBLK;
             const int wrow = 16 * ct + li;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<bf16> fw[KSTEPS];
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                Frag<bf16> fw, fa;
-                fw.v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
-                fa.v = *reinterpret_cast<const bf16x8*>(XN + (16 * rt + li) * Ly::XN_PITCH + (ks * 32 + 8 * g) * 2);
-                acc = mma16(fa, fw, acc);
+            for (int ks = 0; ks < KSTEPS; ++ks)
+                fw[ks].v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks += 2) {
+                acc = mma16(fa_c[ks], fw[ks], acc);
+                acc1 = mma16(fa_c[ks + 1], fw[ks + 1], acc1);
             }
+            acc = acc + acc1;
             float csum = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -380,16 +402,18 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
             Frag<bf16> fa[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8*>(DS + (16 * rt + li) * Ly::HC_PITCH + (ks * 32 + 8 * g) * 2);
+            Frag<bf16> fw2[KT][2];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 const int rw = 16 * (ct + 4 * j) + li;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    Frag<bf16> fw;
-                    fw.v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
-                    yacc[j] = mma16(fa[ks], fw, yacc[j]);
-                }
+                for (int ks = 0; ks < 2; ++ks)
+                    fw2[j][ks].v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
             }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < KT; ++j) yacc[j] = mma16(fa[ks], fw2[j][ks], yacc[j]);
         }
         // u chunk c + 1 into the other buffer (last read two barriers ago)
         if (c + 1 < NC && tid < 384) *reinterpret_cast<uint4*>(HC + ((c + 1) & 1) * 2 * Ly::HC_BYTES + ur * Ly::HC_PITCH + uc * 16) = u_next;

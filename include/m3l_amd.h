@@ -71,6 +71,9 @@ void m3l_set_attn_phase_buffer(void* dev_buf);
  * anything on `stream` consumes parameter gradients (optimizer step, all-reduce) — and keeps every workspace it passed to a backward
  * alive until then.  m3l_amd.parallel.GradSync does both when it is not communicating.  Returns the previous setting / 0. */
 int m3l_set_defer_join(int on);
+/* Diagnostic: 1 = run every weight-gradient kernel on the caller's stream instead of the side stream (no overlap: per-kernel counters and
+ * stand-alone durations are attributable); env M3L_WGRAD_INLINE sets the initial value.  Returns the previous setting. */
+int m3l_set_wgrad_inline(int on);
 int m3l_side_join(void* stream);
 int m3l_side_pending(void);      /* number of un-joined deferred tails (diagnostic / tests) */
 /* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token

@@ -35,6 +35,7 @@ _SIGS = {
     "m3l_set_attn_phase_buffer": (None, [c_p]),
     "m3l_set_t192": (c_i, [c_i]),
     "m3l_set_defer_join": (c_i, [c_i]),
+    "m3l_set_wgrad_inline": (c_i, [c_i]),
     "m3l_side_join": (c_i, [c_p]),
     "m3l_side_pending": (c_i, []),
     "m3l_mask_counts": (c_i, [C.POINTER(Geom), C.c_double, C.POINTER(c_i)]),

@@ -84,6 +84,9 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
         // ------------------------------------------------------------------ DMA wave
         const int srow = lane >> 3, spc = lane & 7;
         auto issue = [&](int blk) {
+#ifdef AB_ABL
+            if (AB_ABL & 1) return;                       // diagnostic build (tools/t192_ablate.sh): no weight stream
+#endif
             const bf16* Wsrc = blk < NB_QKV ? Wqkv + (long)blk * 64 * D : Wo + (long)(blk - NB_QKV) * 64 * D;
             char* dst = WR + (blk % Ly::NSTAGE) * Ly::WBLK;
 #pragma unroll

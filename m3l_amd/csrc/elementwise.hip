@@ -179,6 +179,24 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
     reduce_cols_32x32(part, G, stride, j, j < count, out, accumulate);
 }
 
+// out[0] = (accumulate ? out[0] : 0) + sum_i v[i]: one workgroup, coalesced strided partial sums, fixed-order tree (the loss partials)
+__global__ __launch_bounds__(1024) void reduce_vec_kernel(const float* __restrict__ v, int G, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3072 < G; i += 4096) { a0 += v[i]; a1 += v[i + 1024]; a2 += v[i + 2048]; a3 += v[i + 3072]; }
+    for (; i < G; i += 1024) a0 += v[i];
+    float s = wave_sum((a0 + a1) + (a2 + a3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
 // up to 4 equal-width column segments of one partial slab, each to its own destination (blockIdx.y = segment)
 struct ReduceSegs { float* out[4]; };
 __global__ __launch_bounds__(1024) void reduce_rows_seg_kernel(const float* __restrict__ part, int G, int stride, int width,
@@ -924,9 +942,17 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
 
 // =================================================================================================================
 static int ln_grid(int M) { return cdiv(M, WPB); }
+int m3l_part_blocks(void) {
+    static const int nb = [] {
+        const char* e = getenv("M3L_PART_BLOCKS");
+        const int v = e ? atoi(e) : 1024;
+        return v < 64 ? 64 : (v > M3L_MAX_PARTIAL_BLOCKS ? M3L_MAX_PARTIAL_BLOCKS : v);
+    }();
+    return nb;
+}
 static int part_grid(long rows) {
     long g = (rows + WPB - 1) / WPB;
-    if (g > M3L_MAX_PARTIAL_BLOCKS) g = M3L_MAX_PARTIAL_BLOCKS;
+    if (g > m3l_part_blocks()) g = m3l_part_blocks();
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -946,7 +972,10 @@ int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, 
 }
 
 int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st) {
-    reduce_rows_kernel<<<cdiv(count, 32), 1024, 0, st>>>(part, G, stride, count, out, accumulate);
+    if (count == 1 && stride == 1)
+        reduce_vec_kernel<<<1, 1024, 0, st>>>(part, G, out, accumulate);
+    else
+        reduce_rows_kernel<<<cdiv(count, 32), 1024, 0, st>>>(part, G, stride, count, out, accumulate);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1002,7 +1031,7 @@ int m3l_reduce_rows_seg3(const float* part, int G, int D, float* out0, float* ou
 int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st) {
     M3L_CHECK(M > 0 && N > 0, "colsum: bad shape");
     int G = cdiv(M, 64);
-    if (G > M3L_MAX_PARTIAL_BLOCKS) G = M3L_MAX_PARTIAL_BLOCKS;
+    if (G > m3l_part_blocks()) G = m3l_part_blocks();
     const int rpb = cdiv(M, G);
     G = cdiv(M, rpb);
     ProfScope prof("colsum", M, N, dtype, (double)M * N * (dtype ? 2 : 4), st);
@@ -1268,7 +1297,7 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
     M3L_CHECK(dd % 4 == 0 && dd <= 1024, "unshuffle_bwd: dd=%d must be a multiple of 4, <= 1024", dd);
     (void)masked;
     int rpw = 16;                                       // rows per wave; fewer waves than M3L_MAX_PARTIAL_BLOCKS workgroups
-    while (cdiv(cdiv(rows, rpw), WPB) > M3L_MAX_PARTIAL_BLOCKS) rpw *= 2;
+    while (cdiv(cdiv(rows, rpw), WPB) > m3l_part_blocks()) rpw *= 2;
     const int G = cdiv(cdiv(rows, rpw), WPB);
     const int vpw = cdiv((long)B * nvis, (long)G * WPB);
     const int N = nvis + nmask, nt = n_tac > 0 ? n_tac : 1;

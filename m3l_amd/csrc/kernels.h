@@ -7,7 +7,7 @@
 #include <stdint.h>
 
 #define M3L_MAX_SENSORS 8
-#define M3L_MAX_PARTIAL_BLOCKS 512
+#define M3L_MAX_PARTIAL_BLOCKS 2048      // capacity of the partial-row workspaces; the launch grids use m3l_part_blocks() <= this
 
 // dtype codes: 0 = f32, 1 = bf16
 
@@ -55,6 +55,7 @@ struct PatchGroup {
     int base;                            // token index of the group's first patch
 };
 
+int m3l_part_blocks(void);   // workgroups of the partial-sum kernels (default 1024; env M3L_PART_BLOCKS)
 int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi* epi, hipStream_t st);
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);
 int m3l_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, float* partial_ws, size_t ws_bytes,

@@ -86,9 +86,10 @@ hipEvent_t side_event() {
 // fork(st) orders the library's side stream behind everything queued on `st` and returns it, and end() leaves ONE pending tail event
 // for m3l_side_join; otherwise the work stays on the caller's stream.
 // M3L_WGRAD_INLINE=1: every weight gradient on the caller's stream (no overlap: per-kernel PMC counters attribute cleanly) — diagnostic
+int g_wgrad_inline = -1;      // -1 = environment not read yet
 bool wgrad_inline() {
-    static const bool on = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0;
-    return on;
+    if (g_wgrad_inline < 0) g_wgrad_inline = getenv("M3L_WGRAD_INLINE") != nullptr && atoi(getenv("M3L_WGRAD_INLINE")) > 0 ? 1 : 0;
+    return g_wgrad_inline > 0;
 }
 struct SideSection {
     bool on = false;
@@ -308,6 +309,13 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
 extern "C" {
 
 int m3l_version(void) { return 200; }
+
+// diagnostic switch (bench.py's stand-alone roofline figure, PMC passes): 1 = every weight gradient on the caller's stream
+int m3l_set_wgrad_inline(int on) {
+    const int old = wgrad_inline() ? 1 : 0;
+    g_wgrad_inline = on ? 1 : 0;
+    return old;
+}
 
 int m3l_set_defer_join(int on) {
     const int old = g_defer_join;

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from m3l_amd import _lib as L  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-raw = C.CDLL(L.LIB_PATH)
+raw = C.CDLL(sys.argv[2] if len(sys.argv) > 2 else L.LIB_PATH)
 lib = L.lib()
 dev = "cuda:0"
 B, n, D, H = 256, 48, 192, 3

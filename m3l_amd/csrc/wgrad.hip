@@ -311,7 +311,10 @@ WgPlanHost plan_of(int M, const TnProblem* probs, int count, WgGroup* grp) {
         tiles += cdiv(a, WG_TA) * tb;
     }
     pl.tiles_total = tiles;
-    int S = std::max(1, cu_count() / std::max(1, tiles));
+    // splits over M: M3L_WGRAD_WAVES workgroups per CU in all (1 = one wave of workgroups, each as long as the launch; 2, the default = shorter
+    // workgroups that hand their CU back to the critical path sooner, at the price of more partial slabs)
+    static const int waves = getenv("M3L_WGRAD_WAVES") ? std::max(1, atoi(getenv("M3L_WGRAD_WAVES"))) : 2;
+    int S = std::max(1, waves * cu_count() / std::max(1, tiles));
     S = std::min(S, std::max(1, M / 256));                     // at least 256 rows per split
     pl.rows_per_split = cdiv(cdiv(M, S), 64) * 64;
     pl.S = cdiv(M, pl.rows_per_split);

@@ -923,3 +923,61 @@ def test_two_rank_data_parallel_step_on_one_gpu():
                        cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ranks identical: True" in r.stdout, r.stdout[-2000:]
+
+
+def test_wgrad_inline_switch_is_bit_identical():
+    """m3l_set_wgrad_inline (bench.py's stand-alone roofline pass, the PMC passes): the same kernels on the caller's stream instead of the
+    side stream — every gradient bit-identical, nothing left pending."""
+    from m3l_amd import _lib as L
+    from m3l_amd.parallel import GradSync
+
+    def run(inline):
+        torch.manual_seed(0)
+        enc = VTT(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=192, depth=3, heads=3, mlp_dim=768, num_tactiles=2)
+        mae = VTMAE(encoder=enc, decoder_dim=192, masking_ratio=0.75, decoder_depth=2, decoder_heads=3, num_tactiles=2, compute_dtype="bf16").to(DEV)
+        sync = GradSync(mae)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x = {"image": torch.rand(6, 3, 64, 64, device=DEV, generator=g), "tactile1": torch.rand(6, 3, 32, 32, device=DEV, generator=g),
+             "tactile2": torch.rand(6, 3, 32, 32, device=DEV, generator=g)}
+        noises = [torch.rand(6, 64, device=DEV, generator=g) for _ in range(3)]
+        old = L.lib().m3l_set_wgrad_inline(1 if inline else 0)
+        try:
+            sync.zero_grad()
+            mae(x, mask_noise=noises).backward()
+            if inline:
+                assert L.lib().m3l_side_pending() == 0
+            sync.finish()
+            torch.cuda.synchronize()
+        finally:
+            L.lib().m3l_set_wgrad_inline(old)
+        return sync.flat.clone()
+
+    assert torch.equal(run(False), run(True))
+
+
+def test_attention_block_phase_stamps():
+    """Profiling hook of the forward attention block (m3l_set_attn_phase_buffer, tools/attn_phase_probe.py): six increasing shader-clock
+    stamps per sample while the buffer is set, nothing written once it is cleared, results unchanged."""
+    from m3l_amd import Transformer
+    from m3l_amd import _lib as L
+    torch.manual_seed(0)
+    tf = Transformer(192, 2, 3, 64, 768)
+    tf.compute_dtype = "bf16"
+    tf = tf.to(DEV)
+    B = 9
+    x = torch.randn(B, 48, 192, device=DEV)
+    y0 = tf(x).clone()
+    ts = torch.zeros(B, 8, dtype=torch.int64, device=DEV)
+    L.lib().m3l_set_attn_phase_buffer(ts.data_ptr())
+    try:
+        y1 = tf(x).clone()
+        torch.cuda.synchronize()
+    finally:
+        L.lib().m3l_set_attn_phase_buffer(None)
+    t = ts.cpu()
+    assert bool((t[:, 0] > 0).all()) and bool((t[:, 1:6] > t[:, 0:5]).all()), t
+    ts.zero_()
+    y2 = tf(x)
+    torch.cuda.synchronize()
+    assert int(ts.abs().sum()) == 0
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)

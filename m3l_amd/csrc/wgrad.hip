@@ -51,12 +51,19 @@ struct WgGroup {
 
 // LDS-DMA of one 1-KiB piece (64 lanes x 16 B, lane-linear at lds_dst) through a buffer resource; M0 carries the LDS base and is
 // restored (the compiler reserves it).  Not counted by the compiler: pair with an explicit s_waitcnt vmcnt + barrier.
+template <bool NT = false>
 __device__ __forceinline__ void dma16(int4v rsrc, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
-                 : "memory");
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                     : "memory");
 }
 __device__ __forceinline__ int4v make_rsrc(const void* p, long bytes) {
     const unsigned long a = (unsigned long)p;
@@ -87,7 +94,7 @@ constexpr int WG_NST = 4;                    // ring stages of 32 rows x 8 panel
 constexpr int WG_STAGE = 8 * 4096;
 
 template <int TBT>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs) {
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs, int nt) {
     constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,10 +139,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
         const unsigned base = lds0 + (t % WG_NST) * WG_STAGE;
         if (wave_a) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma16(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+            for (int j = 0; j < 4; ++j) {
+                if (nt) dma16<true>(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+                else dma16<false>(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < TBT; ++j) dma16(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+            for (int j = 0; j < TBT; ++j) {
+                if (nt) dma16<true>(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+                else dma16<false>(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+            }
         }
     };
 
@@ -365,13 +378,14 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
     }
     M3L_CHECK(ws_bytes >= pl.ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
     const int TB = 64 * pl.tbt;
+    static const int wg_nt = getenv("M3L_WGRAD_NT") ? atoi(getenv("M3L_WGRAD_NT")) : 0;     // opt-in: non-temporal operand loads (stand-alone 136 -> 126 us, nothing end to end)
     {
         ProfScope prof(count >= 3 ? "wgrad" : "wgrad_small", M, pl.tiles_total, pl.S, flops, st, bytes);   // grouped layer launches vs single Linears
         const dim3 g1(8 * pl.tiles_total * cdiv(pl.S, 8));
         const size_t lds = (size_t)WG_NST * WG_STAGE;
-        if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
-        else if (pl.tbt == 3) wgrad_kernel<3><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
-        else wgrad_kernel<4><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws);
+        if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
+        else if (pl.tbt == 3) wgrad_kernel<3><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
+        else wgrad_kernel<4><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
     }
     M3L_LAUNCH_CHECK();
     ProfScope prof2("wgrad_reduce", pl.S, pl.tiles_total, count, 0.0, st, (double)pl.ws_bytes);

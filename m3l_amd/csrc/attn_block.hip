@@ -19,6 +19,13 @@
 #include "common.cuh"
 #include "kernels.h"
 
+#ifndef M3L_BODY_INLINE
+#define M3L_BODY_INLINE __forceinline__
+#endif
+#ifndef M3L_BODY_TID
+#define M3L_BODY_TID() ((int)threadIdx.x)     // enc_mega.hip launders it per body call (keeps loop-invariant code motion out of the layer loop)
+#endif
+
 namespace {
 
 constexpr int AB_CW = 12;                 // compute waves: (column tile 0..3) x (row tile 0..2) in the projections, (head, query tile) in attention
@@ -51,8 +58,9 @@ template <int KT> struct AbLayout {
     static_assert(KT == 2 || KT == 3, "vmcnt immediates in the DMA wave are 16 / 24");
 };
 
+// (the body is a device function: attn_block_fwd_kernel wraps it, and enc_mega.hip calls it for every layer of a stack in one launch)
 template <int KT>
-__global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
+__device__ M3L_BODY_INLINE void attn_block_fwd_body(
     const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
     const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
     float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* gl_vp;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = M3L_BODY_TID(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.x;
     const long row0 = (long)b * n;
@@ -362,8 +370,19 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
     stamp(5);
 }
 
+#ifndef M3L_BLOCK_BODIES_ONLY
+template <int KT>
+__global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
+    const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
+    float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
+    float* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
+    attn_block_fwd_body<KT>(x, ln1_w, ln1_b, Wqkv, Wo, bo, ln2_w, ln2_b, eps, n, xn1_out, qkv_out, o_out, lse_out, x1_out, xn2_out, phase_ts);
+}
+
 int g_ab_state = 0;   // 0 = unknown, 1 = on, -1 = off
 unsigned long long* g_attn_phase_ts = nullptr;   // profiling hook: device buffer [B][8] of phase stamps, or null
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of the attention half of a short-sequence layer, dgrad chain only (weight gradients stay with the grouped TN GEMM on the
@@ -391,7 +410,7 @@ template <int KT> struct AbBwdLayout {
 };
 
 template <int KT>
-__global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
+__device__ M3L_BODY_INLINE void attn_block_bwd_body(
     const bf16* __restrict__ dx1t, const float* __restrict__ dres, const float* __restrict__ x, const float* __restrict__ ln1_w,
     const bf16* __restrict__ qkv, const bf16* __restrict__ o, const float* __restrict__ lse, const bf16* __restrict__ WoT,
     const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
     typedef __attribute__((address_space(1))) const void* gl_vp;
     typedef __attribute__((address_space(3))) bf16x4* lds_p4;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = M3L_BODY_TID(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.x;
     const long row0 = (long)b * n;
@@ -821,7 +840,20 @@ __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
     }
 }
 
+#ifndef M3L_BLOCK_BODIES_ONLY
+template <int KT>
+__global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
+    const bf16* __restrict__ dx1t, const float* __restrict__ dres, const float* __restrict__ x, const float* __restrict__ ln1_w,
+    const bf16* __restrict__ qkv, const bf16* __restrict__ o, const float* __restrict__ lse, const bf16* __restrict__ WoT,
+    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+    float* __restrict__ ln_part) {
+    attn_block_bwd_body<KT>(dx1t, dres, x, ln1_w, qkv, o, lse, WoT, WqkvT, eps, n, dqkv_out, dx_out, dxt_out, ln_part);
+}
+#endif
+
 }  // namespace
+
+#ifndef M3L_BLOCK_BODIES_ONLY
 
 // g_ab_state: 0 = unread, -1 = off, otherwise a bit mask: 1 = forward blocks + MLP backward block, 2 = attention backward block too
 static int ab_state() {
@@ -842,6 +874,7 @@ extern "C" int m3l_set_attn_block(int mode) {
 // Profiling hook (tools/attn_phase_probe.py): a device buffer of at least 8 * B uint64 that every later attention-block forward launch
 // fills with the shader-clock stamps of its phase boundaries; NULL switches it off (the default: the kernel then writes nothing).
 extern "C" void m3l_set_attn_phase_buffer(void* dev_buf) { g_attn_phase_ts = reinterpret_cast<unsigned long long*>(dev_buf); }
+unsigned long long* m3l_attn_phase_buffer(void) { return g_attn_phase_ts; }
 
 // 1 when the fused attention-block kernel takes this problem
 int m3l_attn_block_supported(int dtype, int D, int heads, int n, int project_out) {
@@ -897,3 +930,4 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
     M3L_LAUNCH_CHECK();
     return 0;
 }
+#endif  // M3L_BLOCK_BODIES_ONLY

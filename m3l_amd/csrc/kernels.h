@@ -151,6 +151,11 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
 int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres, const float* x, const float* ln1_w, const void* qkv,
                        const void* o, const float* lse, const void* woT, const void* wqkvT, float eps, void* dqkv, float* dx_out, void* dxt_out,
                        float* ln_part, hipStream_t st);
+// whole-stack launches for short sequences (enc_mega.hip): the bodies of the block kernels above, layer after layer in one launch
+#define M3L_MEGA_MAX_LAYERS 16
+int m3l_enc_mega_enabled(void);      // bit 1: forward (env M3L_ENC_MEGA, default 1)
+int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* const* layers, int count, float eps, hipStream_t st);
+unsigned long long* m3l_attn_phase_buffer(void);
 // row-tiled fused half layers for long sequences (t192.hip): 192 token rows per workgroup, any M
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);
 int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,

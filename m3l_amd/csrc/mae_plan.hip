@@ -539,7 +539,24 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, HD) && m3l_gemm_nt_rowln_supported(dt, D, mlp);
     const void* const* tfin = tensors + 11 * c->depth;
     bool final_done = false;
-    for (int l = 0; l < c->depth; ++l) {
+    // short sequences whose every half layer takes a block kernel: the whole stack in ONE launch (enc_mega.hip)
+    int l_begin = 0;
+    if ((m3l_enc_mega_enabled() & 1) && !fuse && c->depth >= 1 && c->depth <= M3L_MEGA_MAX_LAYERS && c->project_out &&
+        m3l_attn_block_supported(dt, D, c->heads, n, c->project_out) && m3l_mlp_block_supported(dt, D, mlp, n) &&
+        !(m3l_mlp_t192_short() && m3l_mlp_t192_supported(dt, D, mlp, M))) {
+        const void* lay[M3L_MEGA_MAX_LAYERS][20];
+        for (int l = 0; l < c->depth; ++l) {
+            TfLayer& L = w.L[l];
+            const void* const* t = tensors + 11 * l;
+            const void* v[20] = {t[0], t[1], L.wqkv, L.wo, t[4], t[5], t[6], L.xn1, L.qkv, L.o, L.lse, L.x1, L.xn2,
+                                 L.w1, t[8], L.w2, t[10], L.u, L.h, L.xout};
+            memcpy(lay[l], v, sizeof(v));
+        }
+        if (m3l_enc_fwd_mega(D, mlp, B, n, x, &lay[0][0], c->depth, LN_EPS, st)) return 1;
+        x = w.L[c->depth - 1].xout;
+        l_begin = c->depth;
+    }
+    for (int l = l_begin; l < c->depth; ++l) {
         TfLayer& L = w.L[l];
         const void* const* t = tensors + 11 * l;
         const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *out_b = (const float*)t[4], *ln2_w = (const float*)t[5],

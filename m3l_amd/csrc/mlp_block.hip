@@ -14,6 +14,13 @@
 #include "common.cuh"
 #include "kernels.h"
 
+#ifndef M3L_BODY_INLINE
+#define M3L_BODY_INLINE __forceinline__
+#endif
+#ifndef M3L_BODY_TID
+#define M3L_BODY_TID() ((int)threadIdx.x)     // enc_mega.hip launders it per body call (keeps loop-invariant code motion out of the layer loop)
+#endif
+
 namespace {
 
 #ifndef MB_ABL
@@ -46,7 +53,7 @@ template <int KT> struct MbLayout {
 };
 
 template <int KT>
-__global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+__device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                                      const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                      const bf16* __restrict__ W2, const float* __restrict__ b2, int n,
                                                                      int mlp, bf16* __restrict__ u_out, bf16* __restrict__ h_out,
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* gl_vp;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = M3L_BODY_TID(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const long row0 = (long)blockIdx.x * n;
     const int RT = (n + 15) >> 4;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* _
 // Same ring / barrier structure as the forward with (W2^T, W1^T) in place of (W1, W2): block 2c = rows 64c.. of W2^T [mlp][D],
 // block 2c + 1 = columns 64c.. of W1^T [D][mlp].  u arrives one chunk ahead through registers.
 template <int KT>
-__global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+__device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt, float* __restrict__ dx,
                                                                      const float* __restrict__ x1, const float* __restrict__ ln2_w,
                                                                      const bf16* __restrict__ u, const bf16* __restrict__ W2T,
                                                                      const bf16* __restrict__ W1T, float eps, int n, int mlp,
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* gl_vp;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = M3L_BODY_TID(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.x;
     const long row0 = (long)b * n;
@@ -499,7 +506,29 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
     }
 }
 
+#ifndef M3L_BLOCK_BODIES_ONLY
+template <int KT>
+__global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+                                                                     const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                                                     const bf16* __restrict__ W2, const float* __restrict__ b2, int n,
+                                                                     int mlp, bf16* __restrict__ u_out, bf16* __restrict__ h_out,
+                                                                     float* __restrict__ xout) {
+    mlp_block_fwd_body<KT>(xn2, x1, W1, b1, W2, b2, n, mlp, u_out, h_out, xout);
+}
+template <int KT>
+__global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+                                                                     const float* __restrict__ x1, const float* __restrict__ ln2_w,
+                                                                     const bf16* __restrict__ u, const bf16* __restrict__ W2T,
+                                                                     const bf16* __restrict__ W1T, float eps, int n, int mlp,
+                                                                     bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
+                                                                     float* __restrict__ cs_part, float* __restrict__ ln_part) {
+    mlp_block_bwd_body<KT>(dxt, dx, x1, ln2_w, u, W2T, W1T, eps, n, mlp, du_out, dx1t_out, cs_part, ln_part);
+}
+#endif
+
 }  // namespace
+
+#ifndef M3L_BLOCK_BODIES_ONLY
 
 int m3l_mlp_block_supported(int dtype, int D, int mlp, int n) {
     return m3l_attn_block_supported(dtype, D, D / 64, n, 1) && mlp % 64 == 0 && mlp >= 64;
@@ -552,3 +581,4 @@ int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float
     M3L_LAUNCH_CHECK();
     return 0;
 }
+#endif  // M3L_BLOCK_BODIES_ONLY

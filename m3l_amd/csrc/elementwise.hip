@@ -333,6 +333,38 @@ __global__ void im2col_kernel(ConvSrc cs, int Bsrc, int Ci, int H, int W, int KH
     col[idx] = from_f32<T>(v);
 }
 
+// 4 x 4 kernels in bf16 (the three strided convolutions of the stem): one thread per (output pixel, input channel) writes that channel's
+// 16 consecutive k = 32 contiguous bytes of the column row; lanes run over ci, so an NHWC source is read in coalesced 2-byte runs and
+// an NCHW fp32 source in 16-byte rows.  (Kpad == Ci * 16: no pad columns.)
+__global__ __launch_bounds__(256) void im2col4_bf16_kernel(ConvSrc cs, int Bsrc, int Ci, int H, int W, int S, int P, int OH, int OW, long total,
+                                                           bf16* __restrict__ col) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (row r, ci), ci fastest
+    if (idx >= total) return;
+    const int ci = (int)(idx % Ci);
+    const long r = idx / Ci;
+    const int ow = (int)(r % OW), oh = (int)((r / OW) % OH);
+    const int b = (int)(r / ((long)OW * OH));
+    bf16x8 out[2];
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+        const int ih = oh * S + kh - P;
+        const bool rok = ih >= 0 && ih < H;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int iw = ow * S + kw - P;
+            float v = 0.f;
+            if (rok && iw >= 0 && iw < W) {
+                if (cs.nchw) v = reinterpret_cast<const float*>(cs.src[b / Bsrc])[(((long)(b % Bsrc) * Ci + ci) * H + ih) * W + iw];
+                else v = (float)reinterpret_cast<const bf16*>(cs.src[0])[(((long)b * H + ih) * W + iw) * Ci + ci];
+            }
+            out[kh >> 1][(kh & 1) * 4 + kw] = (bf16)v;
+        }
+    }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(col + (r * Ci + ci) * 16);
+    dst[0] = out[0];
+    dst[1] = out[1];
+}
+
 // adjoint of im2col in gather form (no atomics) + ReLU mask of the layer input: dX[b,ih,iw,ci] = act > 0 ? sum : 0
 template <typename T>
 __global__ void col2im_relu_kernel(const T* __restrict__ dcol, int Btot, int Ci, int H, int W, int KH, int S, int P, int OH, int OW,
@@ -1086,6 +1118,12 @@ int m3l_im2col(int dtype, const ConvSrc* src, int Bsrc, int Ci, int H, int W, in
                hipStream_t st) {
     const int Btot = src->nchw ? Bsrc * src->nsrc : Bsrc;
     const long total = (long)Btot * OH * OW * Kpad;
+    if (dtype == 1 && KH == 4 && Kpad == Ci * 16) {
+        const long pairs = (long)Btot * OH * OW * Ci;
+        im2col4_bf16_kernel<<<cdiv(pairs, 256), 256, 0, st>>>(*src, Bsrc, Ci, H, W, S, P, OH, OW, pairs, (bf16*)col);
+        M3L_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == 1)
         im2col_kernel<bf16><<<cdiv(total, 256), 256, 0, st>>>(*src, Bsrc, Ci, H, W, KH, S, P, OH, OW, Kpad, total, (bf16*)col);
     else

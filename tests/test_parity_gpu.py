@@ -336,14 +336,16 @@ def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gt
     return mae
 
 
-def test_reference_default_architecture():
+@pytest.mark.parametrize("dt,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 1e-2, 0.15)])
+def test_reference_default_architecture(dt, tol, gtol):
     """M3L's own defaults (train.py:58-67,128-153): dim 256 / depth 4 / heads 4 / mlp 512, decoder 256 / 3 / 4, mask 0.95,
-    early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row), at B = 3 and reduced depth."""
+    early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row), at B = 3 and reduced depth; bf16 also takes the
+    4 x 4 im2col kernel of the EarlyCNN stem."""
     cfg = O.OracleCfg(64, 32, 8, 4, 256, 2, 4, 512, 12, 2, 256, 1, 4, 0.95)
     _parity_vs_oracle(dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=256, depth=2, heads=4, mlp_dim=512,
                            image_channels=12, tactile_channels=12, num_tactiles=2, frame_stack=4),
                       dict(decoder_dim=256, masking_ratio=0.95, decoder_depth=1, decoder_heads=4, num_tactiles=2, early_conv_masking=True,
-                           frame_stack=4), B=3, C=12, hw_img=64, hw_tac=32, k=2, cfg=cfg)
+                           frame_stack=4, compute_dtype=dt), B=3, C=12, hw_img=64, hw_tac=32, k=2, cfg=cfg, tol=tol, gtol=gtol)
 
 
 def test_cfg4_shapes():

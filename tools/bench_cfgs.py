@@ -8,7 +8,11 @@ from m3l_amd import VTMAE, VTT, DinoV2Frozen, DinoCatMAEExtractor
 from m3l_amd.parallel import FlatAdam, GradSync
 dev = torch.device("cuda:0")
 
+ONLY = os.environ.get("M3L_CFGS_ONLY")          # substring of a workload name: run only that one (profiling)
+
 def run(name, enc_kw, mae_kw, B, C, hw_i, hw_t, k, steps=20):
+    if ONLY and ONLY not in name:
+        return None
     torch.manual_seed(0)
     mae = VTMAE(encoder=VTT(**enc_kw), compute_dtype="bf16", **mae_kw).to(dev)
     sync = GradSync(mae); opt = FlatAdam(sync, lr=1e-4)
@@ -29,6 +33,8 @@ run("ref-default 256/4/4 early-conv fs=4 mask .95", dict(image_size=64, tactile_
     dict(decoder_dim=256, masking_ratio=0.95, decoder_depth=3, decoder_heads=4, num_tactiles=2, early_conv_masking=True, frame_stack=4), 512, 12, 64, 32, 2)
 mae = run("cfg5 MAE 70x70 P14 fs=4 384/4/4 dec 384/3/4 mask .8", dict(image_size=70, tactile_size=70, image_patch_size=14, tactile_patch_size=14, dim=384, depth=4, heads=4, mlp_dim=768, image_channels=12, tactile_channels=12, num_tactiles=2, frame_stack=4),
     dict(decoder_dim=384, masking_ratio=0.8, decoder_depth=3, decoder_heads=4, num_tactiles=2, frame_stack=4), 128, 12, 70, 70, 2)
+if mae is None:
+    sys.exit(0)
 dino = DinoV2Frozen().to(dev)
 ext = DinoCatMAEExtractor(dino, mae, 384, False, 4).to(dev).eval()
 obs = {"image": torch.rand(128, 4, 70, 70, 3, device=dev), "tactile": torch.rand(128, 4, 6, 70, 70, device=dev) * 2 - 1}

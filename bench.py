@@ -204,9 +204,9 @@ def main():
     if world > 1 or force_comm or os.environ.get("M3L_FORCE_COMM") == "2":      # "2": process group only (diagnostic)
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        # RCCL kernels on a high-priority stream: a different hardware-queue pool from the compute stream, so collectives can
-        # never be serialised behind compute by HIP's stream -> queue multiplexing
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        # (the gradient all-reduce does not use torch.distributed's NCCL stream at all: m3l_amd.parallel.GradSync has the library call RCCL
+        # on its own side stream — a third kernel-bearing stream costs 7 % of the step at normal priority and 48 % at high priority, so
+        # TORCH_NCCL_HIGH_PRIORITY must stay unset for the fallback path too)
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -284,6 +284,9 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": workload_name,
                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "grad_allreduce": ("none (one rank)" if not sync._comm else
+                                         "RCCL called by the library on its side stream" if getattr(sync, "_direct", False) else
+                                         "torch.distributed (%s)" % dist.get_backend()),
                       "step": "zero_grad + mask + fwd + bwd + grad all-reduce + Adam" if not args.no_optimizer else "fwd + bwd (diagnostic)"},
            "loss": round(float(loss.detach()), 5), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
     if rank == 0:

@@ -79,6 +79,22 @@ int m3l_set_defer_join(int on);
  * stand-alone durations are attributable); env M3L_WGRAD_INLINE sets the initial value.  Returns the previous setting. */
 int m3l_set_wgrad_inline(int on);
 int m3l_side_join(void* stream);
+/* Gradient all-reduce by RCCL called directly, on the library's side stream (comm.hip; RCCL is dlopen'ed at run time — every entry returns
+ * non-zero with m3l_last_error set when it is not available, and the caller falls back to torch.distributed).  One communicator per
+ * process: m3l_comm_unique_id on rank 0 -> 128 bytes to every rank (any channel) -> m3l_comm_init(id, rank, world) on every rank
+ * (collective).  m3l_comm_allreduce(buf, count, after_stream): buf[0..count) fp32 <- sum over ranks, in place, on the side stream behind
+ * everything queued on after_stream and behind the side stream's earlier work; the result is ordered for a consumer by
+ * m3l_side_join(stream).  Every rank issues the same sequence of calls. */
+int m3l_comm_unique_id(void* out128);
+int m3l_comm_init(const void* id128, int rank, int world);
+int m3l_comm_world(void);
+int m3l_comm_allreduce(float* buf, size_t count, void* after_stream);
+int m3l_comm_destroy(void);
+/* building blocks of the above (ordering only): the side stream waits for `after_stream` and is returned / a pending tail is left */
+int m3l_side_fork(void* after_stream, void** side_out);
+int m3l_side_mark_pending(void);
+/* The library's side stream of the current device (hipStream_t, lowest priority, created on first use), or NULL on error. */
+void* m3l_side_stream(void);
 int m3l_side_pending(void);      /* number of un-joined deferred tails (diagnostic / tests) */
 /* row-tiled fused half layers for long sequences (bf16, dim 192, n > 48: the MAE decoder, models/pretrain_models.py:309): 192 token
  * rows per workgroup (t192.hip).  Bit mask: 1 (default) = sequences longer than 48 tokens, 2 = also the MLP halves of short

@@ -38,6 +38,14 @@ _SIGS = {
     "m3l_set_defer_join": (c_i, [c_i]),
     "m3l_set_wgrad_inline": (c_i, [c_i]),
     "m3l_side_join": (c_i, [c_p]),
+    "m3l_side_stream": (c_p, []),
+    "m3l_side_fork": (c_i, [c_p, C.POINTER(c_p)]),
+    "m3l_side_mark_pending": (c_i, []),
+    "m3l_comm_unique_id": (c_i, [c_p]),
+    "m3l_comm_init": (c_i, [c_p, c_i, c_i]),
+    "m3l_comm_world": (c_i, []),
+    "m3l_comm_allreduce": (c_i, [c_p, c_sz, c_p]),
+    "m3l_comm_destroy": (c_i, []),
     "m3l_side_pending": (c_i, []),
     "m3l_mask_counts": (c_i, [C.POINTER(Geom), C.c_double, C.POINTER(c_i)]),
     "m3l_mask_sample": (c_i, [C.POINTER(Geom), C.c_double, c_i, c_p, c_p, c_p, c_p]),

@@ -55,6 +55,8 @@ struct PatchGroup {
     int base;                            // token index of the group's first patch
 };
 
+extern "C" int m3l_side_fork(void* after_stream, void** side_out);
+extern "C" int m3l_side_mark_pending(void);
 int m3l_part_blocks(void);   // workgroups of the partial-sum kernels (default 1024; env M3L_PART_BLOCKS)
 int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi* epi, hipStream_t st);
 size_t m3l_gemm_tn_ws_bytes(int M, int N, int K, int* splits_out);

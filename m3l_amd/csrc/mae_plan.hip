@@ -317,6 +317,33 @@ int m3l_set_wgrad_inline(int on) {
     return old;
 }
 
+// the library's side stream of the current device (created on first use): callers that want to order their own off-critical-path work
+// behind the weight gradients (m3l_amd.parallel issues the gradient all-reduce's bookkeeping there) use it as an external stream
+void* m3l_side_stream(void) {
+    if (side_init()) return nullptr;
+    return (void*)g_side.s;
+}
+
+// building blocks for work that other translation units put on the side stream (comm.hip): fork = the side stream waits for
+// everything queued on `after_stream` so far and is returned; mark_pending = an event behind the side stream's last work joins the
+// pending list that m3l_side_join consumes
+int m3l_side_fork(void* after_stream, void** side_out) {
+    if (side_init()) return 2;
+    hipEvent_t ready = side_event();
+    M3L_HIP(hipEventRecord(ready, (hipStream_t)after_stream));
+    M3L_HIP(hipStreamWaitEvent(g_side.s, ready, 0));
+    *side_out = (void*)g_side.s;
+    return 0;
+}
+int m3l_side_mark_pending(void) {
+    if (side_init()) return 2;
+    hipEvent_t tail = tail_event();
+    M3L_HIP(hipEventRecord(tail, g_side.s));
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    g_pending.push_back(tail);
+    return 0;
+}
+
 int m3l_set_defer_join(int on) {
     const int old = g_defer_join;
     g_defer_join = on ? 1 : 0;

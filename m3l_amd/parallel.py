@@ -96,10 +96,30 @@ class GradSync:
         # are kept alive here until finish()
         self._defer = dev.type == "cuda"
         self._keep = []
-        # HIGH priority: its own hardware-queue class.  A normal-priority helper can share a hardware queue with the compute stream, and
-        # its wait for the side stream's weight gradients then stalls the compute stream behind it (measured at world 1: -7 %).
-        prio = int(os.environ.get("M3L_HELPER_PRIORITY", -1))
-        self._helper = torch.cuda.Stream(device=dev, priority=prio) if (self._comm and dev.type == "cuda") else None
+        # Where the collectives run.  "rccl" (default on a GPU): RCCL called directly by the library on ITS side stream, behind the weight
+        # gradients they wait for anyway — the process keeps exactly two kernel-bearing streams.  "c10d": torch.distributed's own NCCL
+        # stream, reached through a helper stream that joins the compute and the side stream first (CPU / gloo tests, or when RCCL cannot
+        # be initialised).  Measured with a stand-in kernel per bucket on one MI355X (M3L_FAKE_COMM): a third kernel-bearing stream costs
+        # 7 % of the step at normal priority and 48 % at high priority; the same kernels on the side stream 0.8 %.
+        self._direct = False
+        self._helper = None
+        if self._comm and dev.type == "cuda":
+            # (a gloo group on GPU tensors is the one-GPU rehearsal of the multi-rank control flow: RCCL refuses two ranks per device)
+            mode = os.environ.get("M3L_COMM", "rccl" if dist.get_backend(self.group) == "nccl" else "c10d")
+            if mode == "rccl":
+                self._direct = self._init_direct_rccl(dev)
+            if not self._direct:
+                # the helper only carries event waits: HIGH priority, its own hardware-queue class (a normal-priority helper can share a
+                # hardware queue with the compute stream, and its wait for the weight gradients then stalls the compute stream: -7 %)
+                self._helper = torch.cuda.Stream(device=dev, priority=int(os.environ.get("M3L_HELPER_PRIORITY", -1)))
+        self._fake_comm = None
+        fc = os.environ.get("M3L_FAKE_COMM", "0")
+        if self._comm and dev.type == "cuda" and self.world == 1 and fc != "0":
+            if fc == "side":
+                from . import _lib as L
+                self._fake_comm = torch.cuda.ExternalStream(L.lib().m3l_side_stream(), device=dev)
+            else:
+                self._fake_comm = torch.cuda.Stream(device=dev, priority=-1 if fc == "1" else 0)
         self.params = [p for _, p in named]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
@@ -107,6 +127,34 @@ class GradSync:
             module._sinks.update(heads=(self, 0), glue=(self, 2), embed=(self, 4))
             module.decoder._sink = (self, 1)
             module.encoder.transformer._sink = (self, 3)
+
+    def _init_direct_rccl(self, dev) -> bool:
+        """One RCCL communicator for this process, created through the library (m3l_comm_init); the 128-byte id travels over the
+        torch.distributed group that already exists.  False (with a warning) if RCCL is not available: the c10d path takes over."""
+        import ctypes as C
+        import warnings
+        from . import _lib as L
+        lib = L.lib()
+        rank = dist.get_rank(self.group)
+        ident = C.create_string_buffer(128)
+        ok = 1
+        if rank == 0:
+            ok = 1 if lib.m3l_comm_unique_id(ident) == 0 else 0
+        box = [bytes(ident.raw) if ok else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        if box[0] is None:
+            warnings.warn("m3l_amd: RCCL not available to the library (%s); gradient all-reduce through torch.distributed" % L.last_error())
+            return False
+        with torch.cuda.device(dev):
+            rc = lib.m3l_comm_init(C.create_string_buffer(box[0], 128), rank, self.world)
+        flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)        # all ranks take the same path
+        if float(flag.item()) < 1.0:
+            warnings.warn("m3l_amd: m3l_comm_init failed (%s); gradient all-reduce through torch.distributed" % L.last_error())
+            return False
+        return True
 
     def zero_grad(self):
         self.flat.zero_()
@@ -127,6 +175,17 @@ class GradSync:
                 if a <= end < b:
                     end, grew = b, True
         if end > self._sent_end and (flush or end - self._sent_end >= self.min_bucket_elems or end == self.flat.numel()):
+            if self._direct:
+                # in place, on the library's side stream: behind the compute stream's work so far (event) and behind the weight gradients
+                # already queued there; finish() joins the side stream before the optimizer reads the sums
+                from . import _lib as L
+                seg = self.flat[self._sent_end:end]
+                L.check(L.lib().m3l_comm_allreduce(seg.data_ptr(), seg.numel(), torch.cuda.current_stream().cuda_stream), "m3l_comm_allreduce")
+                if self._fake_comm is not None:
+                    with torch.cuda.stream(self._fake_comm):
+                        seg.mul_(1.0)
+                self._sent_end = end
+                return
             if self._helper is not None:
                 # the collective must see the compute stream's gradients AND the weight gradients still on the library's side stream:
                 # both are joined onto a helper stream, the all-reduce is issued from there, the compute stream runs on
@@ -135,6 +194,13 @@ class GradSync:
                 L.check(L.lib().m3l_side_join(self._helper.cuda_stream), "m3l_side_join")
                 with torch.cuda.stream(self._helper):
                     work = dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self._fake_comm is not None:
+                        # rehearsal only (M3L_FAKE_COMM=1 at world size 1, where RCCL launches nothing): a kernel of the collective's size
+                        # on a third, high-priority stream, ordered like c10d orders its own stream
+                        self._fake_comm.wait_stream(self._helper)
+                        with torch.cuda.stream(self._fake_comm):
+                            self.flat[self._sent_end:end].mul_(1.0)
+                        self._helper.wait_stream(self._fake_comm)
             else:
                 work = dist.all_reduce(self.flat[self._sent_end:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append(work)
@@ -172,7 +238,7 @@ class GradSync:
             self._keep.clear()
         for w in self._works:
             w.wait()
-        if self._works and self.world > 1:
+        if (self._works or self._direct) and self.world > 1:
             self.flat.mul_(1.0 / self.world)       # SUM then scale: works on every backend (gloo has no AVG)
         self._works = []
 

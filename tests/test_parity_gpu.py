@@ -522,7 +522,8 @@ def test_train_iterations_replay_buffer():
     assert l1 < l0
 
 
-def test_rccl_path_world1_matches_local():
+@pytest.mark.parametrize("comm", ["rccl", "c10d"])
+def test_rccl_path_world1_matches_local(comm, monkeypatch):
     """The multi-GPU step (GradSync buckets + chunked transformer backward + RCCL all-reduce on its own stream + FlatAdam)
     rehearsed on ONE GPU: backend "nccl" (= RCCL) at world size 1 with force_comm, so every collective is really issued and
     fenced; parameters after 3 steps must equal the no-communication run bit for bit (SUM over one rank, x 1/1)."""
@@ -537,6 +538,8 @@ def test_rccl_path_world1_matches_local():
                     compute_dtype="bf16").to(DEV)
         sync = GradSync(mae, force_comm=force)
         assert sync._comm == force
+        if force:      # "rccl": the library's own RCCL communicator on its side stream; "c10d": torch.distributed's stream via the helper
+            assert sync._direct == (comm == "rccl") and (sync._helper is None) == (comm == "rccl")
         opt = FlatAdam(sync, lr=1e-3)
         g = torch.Generator(device=DEV).manual_seed(5)
         x = {"image": torch.rand(8, 3, 32, 32, device=DEV, generator=g), "tactile1": torch.rand(8, 3, 16, 16, device=DEV, generator=g),
@@ -550,6 +553,7 @@ def test_rccl_path_world1_matches_local():
         torch.cuda.synchronize()
         return sync.flat_params.clone(), sync.flat.clone()
 
+    monkeypatch.setenv("M3L_COMM", comm)
     p0, g0 = run(False)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29547")

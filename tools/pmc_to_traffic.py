@@ -92,7 +92,8 @@ if st:
     for r in rows[:3]:
         name = r["Name"]
         key = name.split("(")[0].split("<")[0].split("::")[-1].strip()
-        key = next((sub for sub in ("wgrad_reduce_kernel", "wgrad_kernel", "ln_bwd_kernel", "mlp_block_bwd_kernel", "mlp_block_fwd_kernel", "attn_block_bwd_kernel",
+        key = next((sub for sub in ("enc_fwd_mega_kernel", "attn_t192_bwd_kernel", "attn_t192_fwd_kernel", "qkv_bwd_t192_kernel",
+                                    "wgrad_reduce_kernel", "wgrad_kernel", "ln_bwd_kernel", "mlp_block_bwd_kernel", "mlp_block_fwd_kernel", "attn_block_bwd_kernel",
                                     "attn_block_fwd_kernel", "mlp_t192_bwd_kernel", "mlp_t192_fwd_kernel", "gemm_nt_glds_kernel") if sub in name), key)
         nf, sf, nw, sw = per_launch(key)
         avg_us = float(r["AverageNs"]) / 1e3

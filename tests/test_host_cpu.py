@@ -167,3 +167,14 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     nm, nmi, nmt = O.mask_counts(0.95, 64, 128, 2)
     assert f"ref  mask 0.95: masked {nm} unmasked {192 - nm} (image {nmi}, per sensor {nmt})" in out
     assert "error convention:" in out and "must be a multiple" in out
+
+
+def test_comm_entry_points_fail_loudly_before_init():
+    """comm.hip (gradient all-reduce by RCCL on the library's side stream): no communicator before m3l_comm_init, and an all-reduce without
+    one returns an error code with a message instead of touching anything."""
+    from m3l_amd import _lib as L
+    lib = L.lib()
+    assert lib.m3l_comm_world() == 0
+    rc = lib.m3l_comm_allreduce(None, 0, None)
+    assert rc != 0 and "m3l_comm_init" in L.last_error()
+    assert lib.m3l_comm_destroy() == 0

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__((TileCfg<12, 1>::THREADS)) void attn_t192_bwd_kerne
 }  // namespace
 
 // g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip),
-// 4 = the 192-row kernels that are only chosen for large M (>= 200 tiles) at any M (tests)
+// 4 = the 192-row kernels that are only chosen for large M (>= T192_MIN_TILES tiles) at any M (tests)
 static int g_t192 = 0;
 static int t192_state() {
     if (!g_t192) {
@@ -1045,7 +1045,12 @@ int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M) {
 }
 
 // tile shape for M rows: 192-row tiles while they give ~a workgroup per CU, 48-row tiles (two chunk parities) below that
-static int t192_tt(int M) { return cdiv(M, 192) >= 200 ? 12 : 3; }
+// 192-row tiles once they fill half the CUs (cfg 4's decoder: 151 tiles, +2 % over 48-row tiles; env M3L_T192_MIN_TILES)
+static int t192_min_tiles() {
+    static const int v = getenv("M3L_T192_MIN_TILES") ? atoi(getenv("M3L_T192_MIN_TILES")) : 128;
+    return v;
+}
+static int t192_tt(int M) { return cdiv(M, 192) >= t192_min_tiles() ? 12 : 3; }
 int m3l_mlp_t192_tiles(int M) { return cdiv(M, 16 * t192_tt(M)); }
 
 #define T192_DISPATCH(TTV, CALL)                                          \
@@ -1072,7 +1077,7 @@ int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const voi
 
 // the same with the attention half's tail in front (x1 = x + o Wo^T + bo, xn2 = LN2(x1)): one launch for three of the per-op path
 int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M) {
-    return m3l_mlp_t192_supported(dtype, D, mlp, M) && HD == T_D && (cdiv(M, 192) >= 200 || (g_t192 & 4));
+    return m3l_mlp_t192_supported(dtype, D, mlp, M) && HD == T_D && (cdiv(M, 192) >= t192_min_tiles() || (g_t192 & 4));
 }
 int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
                                const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,
@@ -1109,7 +1114,7 @@ int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1
 }
 
 int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M) {
-    return t192_state() > 0 && dtype == 1 && D == T_D && K % 64 == 0 && K >= 64 && (cdiv(M, 192) >= 200 || (g_t192 & 4));   // bit 4: any M (tests)
+    return t192_state() > 0 && dtype == 1 && D == T_D && K % 64 == 0 && K >= 64 && (cdiv(M, 192) >= t192_min_tiles() || (g_t192 & 4));   // bit 4: any M (tests)
 }
 int m3l_qkv_bwd_t192_tiles(int M) { return cdiv(M, 192); }
 
@@ -1129,7 +1134,7 @@ int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float
 
 int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B) {
     static const int attn_on = getenv("M3L_T192_ATTN") ? atoi(getenv("M3L_T192_ATTN")) : 1;      // 0: per-op attention (A/B measurements)
-    return attn_on > 0 && t192_state() > 0 && dtype == 1 && D == T_D && heads == 3 && n > 48 && n <= 192 && (B >= 200 || (g_t192 & 4));
+    return attn_on > 0 && t192_state() > 0 && dtype == 1 && D == T_D && heads == 3 && n > 48 && n <= 192 && (B >= t192_min_tiles() || (g_t192 & 4));
 }
 int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
                       void* o, float* lse, hipStream_t st) {

@@ -231,7 +231,7 @@ def main():
         sync.zero_grad()
         loss = mae(x)                 # mask noise drawn on the device with torch.rand, as the reference does
         loss.backward()
-        sync.finish()
+        sync.finish(defer_scale=not args.no_optimizer)     # the 1 / world of the SUM all-reduce is folded into the Adam launch
         if not args.no_optimizer:
             opt.step()
         return loss
@@ -287,6 +287,8 @@ def main():
                       "grad_allreduce": ("none (one rank)" if not sync._comm else
                                          "RCCL called by the library on its side stream" if getattr(sync, "_direct", False) else
                                          "torch.distributed (%s)" % dist.get_backend()),
+                      "rccl_ranks": int(_lib.lib().m3l_comm_world()) if getattr(sync, "_direct", False) else 0,
+                      "rccl_probe_sum": getattr(sync, "rccl_probe", None),     # all-reduce of (rank + 1) by the library's communicator = N (N + 1) / 2
                       "step": "zero_grad + mask + fwd + bwd + grad all-reduce + Adam" if not args.no_optimizer else "fwd + bwd (diagnostic)"},
            "loss": round(float(loss.detach()), 5), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
     if rank == 0:

@@ -85,7 +85,9 @@ int m3l_side_join(void* stream);
  * (collective).  m3l_comm_allreduce(buf, count, after_stream): buf[0..count) fp32 <- sum over ranks, in place, on the side stream behind
  * everything queued on after_stream and behind the side stream's earlier work; the result is ordered for a consumer by
  * m3l_side_join(stream).  Every rank issues the same sequence of calls. */
+int m3l_comm_available(void);     /* local probe, no communication: 0 = RCCL loads in this process (agree on it across ranks BEFORE m3l_comm_init) */
 int m3l_comm_unique_id(void* out128);
+/* a repeated call with the same (rank, world) keeps the live communicator; a different (rank, world) is refused until m3l_comm_destroy */
 int m3l_comm_init(const void* id128, int rank, int world);
 int m3l_comm_world(void);
 int m3l_comm_allreduce(float* buf, size_t count, void* after_stream);
@@ -209,13 +211,19 @@ int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* imag
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream);
 /* the same with the observation dtype (0 = f32, 1 = uint8: raw camera / sensor frames, no host-side cast) and the reference's
  * normalisation arguments: out = (x - lo) / (hi - lo), fp32 IEEE arithmetic as utils/pretrain_utils.py:28-30,47-49 */
-int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
-                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+/* lo / hi are the reference's Python numbers, i.e. doubles: the kernel subtracts (float)lo and divides by (float)(hi - lo), the span
+ * formed in double and rounded ONCE, exactly as `tensor / (hi - lo)` does (bit-exact for ranges like [0.1, 0.3] too) */
+int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, double img_lo, double img_hi, float* image_nchw,
+                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, double tac_lo, double tac_hi,
                  float* const* tactile_out, void* stream);
 
 /* ---- torch.optim.Adam semantics (models/ppo_mae.py:182-183) over one flat fp32 buffer of n elements; step counts from 1 */
 int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, void* stream);
+/* gradients read as grad_scale * grads[i]: the 1 / world of a SUM all-reduce folded into the update (grad_scale = 1 is bit-identical
+ * to m3l_adam_step) */
+int m3l_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* graph-capturable form: the step counter lives on the device (int, incremented by the call) together with the two bias
  * corrections (float[2] scratch), so a captured launch stays correct on every replay (torch's Adam(capturable=True)) */
 int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

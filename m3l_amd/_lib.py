@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libm3l_amd.so")
+# M3L_LIB_PATH: another build of the same library (A/B of two builds in one job: tools/ab_libs.sh); default = the in-tree library
+LIB_PATH = os.environ.get("M3L_LIB_PATH") or os.path.join(_HERE, "lib", "libm3l_amd.so")
 
 c_p = C.c_void_p
 c_i = C.c_int
@@ -41,6 +42,7 @@ _SIGS = {
     "m3l_side_stream": (c_p, []),
     "m3l_side_fork": (c_i, [c_p, C.POINTER(c_p)]),
     "m3l_side_mark_pending": (c_i, []),
+    "m3l_comm_available": (c_i, []),
     "m3l_comm_unique_id": (c_i, [c_p]),
     "m3l_comm_init": (c_i, [c_p, c_i, c_i]),
     "m3l_comm_world": (c_i, []),
@@ -81,9 +83,10 @@ _SIGS = {
     "m3l_gather_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "m3l_scatter_tokens": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "m3l_vt_load": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "m3l_vt_load2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, C.c_float, C.c_float, c_p, c_p, c_i, c_i, c_i, c_i, c_i, C.c_float, C.c_float, c_p, c_p]),
+    "m3l_vt_load2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_p, c_p, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_p, c_p]),
     "m3l_adam_step_dev": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_p, c_p, c_p]),
     "m3l_adam_step": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, c_p]),
+    "m3l_adam_step_scaled": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, C.c_float, c_p]),
     "m3l_prof_begin": (None, [C.c_char_p, c_i]),
     "m3l_prof_end": (None, []),
     "m3l_prof_event_overhead_us": (C.c_double, [c_p, c_i]),

@@ -35,7 +35,8 @@ struct Rccl {
 std::mutex g_comm_mu;
 Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
-int g_comm_world = 0;
+int g_comm_world = 0, g_comm_rank = -1;
+unsigned char g_comm_id[128];
 
 int rccl_load() {
     if (g_rccl.h) return 0;
@@ -79,30 +80,50 @@ int m3l_comm_unique_id(void* out128) {
     return 0;
 }
 
-// collective over all ranks (one process per GPU, the GPU already selected with hipSetDevice / torch.cuda.set_device)
+// Local probe, no communication: 0 when RCCL can be loaded in this process.  Every rank calls it and the ranks agree on the result
+// (a MIN all-reduce over the channel they already share) BEFORE anyone enters the collective m3l_comm_init — a rank that cannot load
+// RCCL must not leave the others blocked inside ncclCommInitRank.
+int m3l_comm_available(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    return rccl_load() ? 1 : 0;
+}
+
+// collective over all ranks (one process per GPU, the GPU already selected with hipSetDevice / torch.cuda.set_device).  One communicator
+// per process: a second call with the same (world, rank) keeps the existing communicator (a second GradSync in the process shares it; the
+// id is ignored); a call that asks for a different world / rank while one is live is refused — destroy it first (m3l_comm_destroy).
 int m3l_comm_init(const void* id128, int rank, int world) {
     std::lock_guard<std::mutex> lock(g_comm_mu);
-    if (rccl_load()) return 1;
     M3L_CHECK(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d of %d", rank, world);
+    M3L_CHECK(id128 != nullptr, "comm_init: null id");
     if (g_comm) {
-        M3L_NCCL(g_rccl.CommDestroy(g_comm));
-        g_comm = nullptr;
+        M3L_CHECK(g_comm_world == world && g_comm_rank == rank,
+                  "comm_init: a communicator for rank %d of %d is live in this process; m3l_comm_destroy() it before asking for rank %d of %d",
+                  g_comm_rank, g_comm_world, rank, world);
+        return 0;
     }
+    if (rccl_load()) return 1;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     M3L_NCCL(g_rccl.CommInitRank(&g_comm, world, id, rank));
     g_comm_world = world;
+    g_comm_rank = rank;
+    memcpy(g_comm_id, id128, sizeof(g_comm_id));
     return 0;
 }
 
-int m3l_comm_world(void) { return g_comm ? g_comm_world : 0; }
+int m3l_comm_world(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    return g_comm ? g_comm_world : 0;
+}
 
 int m3l_comm_destroy(void) {
     std::lock_guard<std::mutex> lock(g_comm_mu);
     if (g_comm) {
-        M3L_NCCL(g_rccl.CommDestroy(g_comm));
+        ncclComm_t c = g_comm;
         g_comm = nullptr;
         g_comm_world = 0;
+        g_comm_rank = -1;
+        M3L_NCCL(g_rccl.CommDestroy(c));
     }
     return 0;
 }
@@ -112,6 +133,7 @@ int m3l_comm_destroy(void) {
 // the span).  Leaves a pending tail: m3l_side_join(stream) orders whatever consumes the result (the optimizer step).  Ranks must
 // issue the same sequence of calls.
 int m3l_comm_allreduce(float* buf, size_t count, void* after_stream) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);          // against a concurrent m3l_comm_destroy / m3l_comm_init
     M3L_CHECK(g_comm != nullptr, "comm_allreduce: m3l_comm_init has not been called");
     hipStream_t side = nullptr;
     if (m3l_side_fork(after_stream, (void**)&side)) return 2;

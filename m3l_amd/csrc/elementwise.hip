@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void tokens_assemble_bwd_kernel(const float* _
 // models/ppo_mae.py:182-183): same update rule and operation order as torch's, one launch for all 7.3 M parameters.
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                 const float* __restrict__ bc_dev) {
+                                 const float* __restrict__ bc_dev, float gscale) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     if (bc_dev) {            // graph-capturable form: bias corrections of the device-side step counter
@@ -469,7 +469,7 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
         f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gr = gg[j] + wd * pp[j];
+            const float gr = gg[j] * gscale + wd * pp[j];                // gscale: 1 / world of a SUM all-reduce (1.0f is exact)
             mm[j] = mm[j] + (gr - mm[j]) * (1.0f - b1);                 // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
             vv[j] = vv[j] * b2 + (1.0f - b2) * gr * gr;
             const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
@@ -480,7 +480,7 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
         *reinterpret_cast<f32x4*>(v + i) = vv;
     } else {
         for (long k = i; k < n; ++k) {
-            const float gr = g[k] + wd * p[k];
+            const float gr = g[k] * gscale + wd * p[k];
             m[k] = m[k] + (gr - m[k]) * (1.0f - b1);
             v[k] = v[k] * b2 + (1.0f - b2) * gr * gr;
             p[k] = p[k] - (lr / bc1) * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
@@ -1164,11 +1164,11 @@ int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac,
 }
 
 int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
-                  hipStream_t st) {
+                  float gscale, hipStream_t st) {
     M3L_CHECK(n > 0 && step >= 1, "adam: n=%ld step=%d", n, step);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
-    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, nullptr);
+    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, nullptr, gscale);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1178,7 +1178,7 @@ int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, floa
     M3L_CHECK(n > 0 && step_dev && bc_dev, "adam (device step): n=%ld", n);
     adam_bias_kernel<<<1, 1, 0, st>>>(step_dev, b1, b2, bc_dev);
     M3L_LAUNCH_CHECK();
-    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, 1.0f, 1.0f, bc_dev);
+    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, 1.0f, 1.0f, bc_dev, 1.0f);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1192,30 +1192,30 @@ int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_de
     return 0;
 }
 
-int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
-                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_span, float* image_nchw,
+                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_span,
                        float* const* tactile_out, hipStream_t st) {
     if (image_nhwc) {
-        M3L_CHECK(img_hi != img_lo, "vt_load: empty image normalisation range");
+        M3L_CHECK(img_span != 0.f, "vt_load: empty image normalisation range");
         const long total = (long)B * C * H * W;
         if (image_u8)
-            vt_image_kernel<uint8_t><<<cdiv(total, 256), 256, 0, st>>>((const uint8_t*)image_nhwc, B, H, W, C, img_lo, img_hi - img_lo, image_nchw);
+            vt_image_kernel<uint8_t><<<cdiv(total, 256), 256, 0, st>>>((const uint8_t*)image_nhwc, B, H, W, C, img_lo, img_span, image_nchw);
         else
-            vt_image_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)image_nhwc, B, H, W, C, img_lo, img_hi - img_lo, image_nchw);
+            vt_image_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)image_nhwc, B, H, W, C, img_lo, img_span, image_nchw);
         M3L_LAUNCH_CHECK();
     }
     if (tactile) {
         M3L_CHECK(n_sensors >= 1 && n_sensors <= M3L_MAX_SENSORS, "vt_load: n_sensors=%d", n_sensors);
-        M3L_CHECK(tac_hi != tac_lo, "vt_load: empty tactile normalisation range");
+        M3L_CHECK(tac_span != 0.f, "vt_load: empty tactile normalisation range");
         VtTactileOut o;
         for (int s = 0; s < n_sensors; ++s) o.p[s] = tactile_out[s];
         const long total = (long)B * 3 * n_sensors * frame_stack * th * tw;
         if (tactile_u8)
             vt_tactile_kernel<uint8_t><<<cdiv(total, 256), 256, 0, st>>>((const uint8_t*)tactile, B, th, tw, n_sensors, frame_stack, tac_lo,
-                                                                         tac_hi - tac_lo, o);
+                                                                         tac_span, o);
         else
             vt_tactile_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)tactile, B, th, tw, n_sensors, frame_stack, tac_lo,
-                                                                       tac_hi - tac_lo, o);
+                                                                       tac_span, o);
         M3L_LAUNCH_CHECK();
     }
     return 0;

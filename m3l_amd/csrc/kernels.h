@@ -198,8 +198,8 @@ int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
 int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
 int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
-int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
-                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_span, float* image_nchw,
+                       const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_span,
                        float* const* tactile_out, hipStream_t st);
 struct ConvSrc {
     const void* src[M3L_MAX_SENSORS];   // nchw: f32 [B, Ci, H, W] per source (sources concatenated on batch); else one NHWC compute-type [Btot*H*W, Ci]
@@ -214,7 +214,7 @@ int k_tokens_assemble(const float* img_tok, const float* tac_tok, int B, int D, 
 int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac, int k, float* d_img, float* d_tac, float* part_ws,
                             float* dmod, int accumulate, hipStream_t st);
 int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
-                  hipStream_t st);
+                  float gscale, hipStream_t st);
 int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
                       int* step_dev, float* bc_dev, hipStream_t st);
 int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,

@@ -1394,19 +1394,27 @@ int m3l_scatter_tokens(const float* src, int B, int N, int D, const int64_t* idx
 }
 int m3l_vt_load(const float* image_nhwc, int B, int H, int W, int C, float* image_nchw, const float* tactile, int th, int tw,
                 int n_sensors, int frame_stack, float* const* tactile_out, void* stream) {
-    return m3l_vt_load_launch(image_nhwc, 0, B, H, W, C, 0.f, 1.f, image_nchw, tactile, 0, th, tw, n_sensors, frame_stack, -1.f, 1.f, tactile_out,
+    return m3l_vt_load_launch(image_nhwc, 0, B, H, W, C, 0.f, 1.f, image_nchw, tactile, 0, th, tw, n_sensors, frame_stack, -1.f, 2.f, tactile_out,
                               (hipStream_t)stream);
 }
-int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_hi, float* image_nchw,
-                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_hi,
+int m3l_vt_load2(const void* image_nhwc, int image_u8, int B, int H, int W, int C, double img_lo, double img_hi, float* image_nchw,
+                 const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, double tac_lo, double tac_hi,
                  float* const* tactile_out, void* stream) {
-    return m3l_vt_load_launch(image_nhwc, image_u8, B, H, W, C, img_lo, img_hi, image_nchw, tactile, tactile_u8, th, tw, n_sensors, frame_stack,
-                              tac_lo, tac_hi, tactile_out, (hipStream_t)stream);
+    // utils/pretrain_utils.py:28-30,47-49: `tensor - lo` rounds the Python double lo to fp32; `/ (hi - lo)` forms the span in double
+    // and rounds it to fp32 once
+    return m3l_vt_load_launch(image_nhwc, image_u8, B, H, W, C, (float)img_lo, (float)(img_hi - img_lo), image_nchw, tactile, tactile_u8, th, tw,
+                              n_sensors, frame_stack, (float)tac_lo, (float)(tac_hi - tac_lo), tactile_out, (hipStream_t)stream);
 }
 
 int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, void* stream) {
-    return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+    return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, 1.0f, (hipStream_t)stream);
+}
+// the same with the gradients read as grad_scale * grads[i] (data parallel: the 1 / world of a SUM all-reduce folded into the update —
+// no separate pass over the gradient buffer)
+int m3l_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
 }
 
 int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

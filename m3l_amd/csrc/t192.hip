@@ -1050,7 +1050,7 @@ static int t192_min_tiles() {
     static const int v = getenv("M3L_T192_MIN_TILES") ? atoi(getenv("M3L_T192_MIN_TILES")) : 128;
     return v;
 }
-static int t192_tt(int M) { return cdiv(M, 192) >= t192_min_tiles() ? 12 : 3; }
+static int t192_tt(int M) { return (cdiv(M, 192) >= t192_min_tiles() || (t192_state() > 0 && (g_t192 & 4))) ? 12 : 3; }   // bit 4: 192-row tiles at any M (tests)
 int m3l_mlp_t192_tiles(int M) { return cdiv(M, 16 * t192_tt(M)); }
 
 #define T192_DISPATCH(TTV, CALL)                                          \

@@ -102,6 +102,10 @@ def _grad_targets(sink, params, used=None):
                                    "all-reduced (the first ones have already travelled); call finish() + step() + zero_grad() per backward, "
                                    "or build the GradSync without communication for gradient accumulation")
             direct = False
+            # the first backward's weight gradients may still be writing these very views on the library's side stream (deferred join):
+            # autograd's accumulate into them, on this stream, must come after
+            if sync._defer:
+                L.check(L.lib().m3l_side_join(_stream()), "m3l_side_join")
         else:
             sync._written.update(ids)
     out = []

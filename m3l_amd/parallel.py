@@ -5,11 +5,15 @@ capability here: samples are independent, so the only exc
 gradients (7.28 M fp32 = 29 MB for the ViT-Tiny config), averaged over ranks.
 
 Design for MI355X: all gradients live in ONE flat fp32 buffer ordered as the backward produces them
-(heads -> decoder -> enc/dec glue -> encoder -> patch embed); `.grad` of every parameter is a view into it.  When the
-last parameter of a bucket has been accumulated by autograd, that bucket's slice is all-reduced asynchronously —
-torch.distributed (backend "nccl" == RCCL on ROCm) runs it on its own HIP stream, fenced by events against the compute
-stream — so the decoder's 7 MB travel while the encoder backward is still computing.  Parameters that never receive a
-gradient under sincos encodings (encoder.pos_embedding, decoder_pos_emb) are excluded (`grad is None`).
+(heads -> decoder -> enc/dec glue -> encoder -> patch embed -> learned position tables); `.grad` of every parameter is a view
+into it and the HIP backward writes it in place.  Once the finished prefix of the buffer holds >= 4 MB, that slice is all-reduced
+asynchronously by RCCL called DIRECTLY by the library (csrc/comm.hip) on the library's own low-priority side stream — behind the
+weight gradients it waits for anyway, event-fenced against the compute stream — so the decoder's 7 MB travel while the encoder
+backward is still computing and the process keeps exactly two kernel-bearing streams (a third one, e.g. torch.distributed's NCCL
+stream, costs 7-48 % of the step on this stack: DESIGN.md section 6).  torch.distributed carries only the 128-byte communicator id and
+is the fallback / the CPU (gloo) path.  Parameters that never receive a gradient under sincos encodings (encoder.pos_embedding,
+decoder_pos_emb) are excluded (`grad is None`); with use_sincosmod_encodings=False they are trained (pretrain_models.py:218-219,
+280-287) and own the trailing span of the buffer (their gradient arrives through autograd after the embed / glue backward).
 """
 import os
 import re
@@ -27,6 +31,8 @@ def _bucket_of(name: str) -> int:
         return 2
     if name.startswith("encoder.transformer"):
         return 3
+    if name in GradSync.SKIP:
+        return 5    # learned position tables (use_sincosmod_encodings=False): final only when the whole backward is
     return 4        # patch embed / EarlyCNN stems, encoder modality embedding
 
 
@@ -44,16 +50,17 @@ class GradSync:
     SKIP = ("encoder.pos_embedding", "decoder_pos_emb.weight")
 
     def __init__(self, module: torch.nn.Module, process_group=None, force_comm=False):
-        if not getattr(module, "use_sincosmod_encodings", True):
-            raise NotImplementedError("GradSync lays the flat buffer out for use_sincosmod_encodings=True (the learned position tables "
-                                      "receive their gradient through autograd, after the bucket they would belong to is reported done)")
+        # learned position tables: unused (no gradient, excluded) under sincos encodings, trained otherwise — then they get the trailing
+        # span of the buffer: autograd accumulates their gradient (the batch sum of the token gradients, functional._pos_grads) into the
+        # flat views after the embed / glue backward, and finish() sends the span with the tail
+        learned_pos = not getattr(module, "use_sincosmod_encodings", True)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_comm: issue the collectives even at world size 1 (rehearses the RCCL stream / event path on a one-GPU box)
         self._comm = self.world > 1 or (force_comm and dist.is_initialized())
         seen, named = set(), []
         for name, p in module.named_parameters():            # named_parameters() already de-duplicates shared tensors
-            if id(p) in seen or not p.requires_grad or name in self.SKIP:
+            if id(p) in seen or not p.requires_grad or (name in self.SKIP and not learned_pos):
                 continue
             seen.add(id(p))
             named.append((name, p))
@@ -88,6 +95,8 @@ class GradSync:
             count += 1
         self.buckets.append([start, off, count])
         self._works = []
+        self._unscaled = False                                 # a SUM all-reduce has been issued since the last scale / zero_grad()
+        self._pending_scale = 1.0                              # finish(defer_scale=True): 1 / world left for the optimizer to fold in
         self._reduced = set()
         self._written = set()                                  # id(param) written directly by a backward since zero_grad()
         # the last weight gradients of every transformer backward (chunk) stay on the library's side stream past the end of the
@@ -136,6 +145,19 @@ class GradSync:
         from . import _lib as L
         lib = L.lib()
         rank = dist.get_rank(self.group)
+
+        def all_agree(ok: bool) -> bool:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            if self.world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return float(flag.item()) >= 1.0
+        # (1) every rank probes RCCL locally and the ranks agree BEFORE anyone enters the collective ncclCommInitRank: a rank that
+        # cannot load RCCL would otherwise leave the others blocked inside it
+        if not all_agree(lib.m3l_comm_available() == 0):
+            warnings.warn("m3l_amd: RCCL not available to the library on every rank (%s); gradient all-reduce through torch.distributed" % L.last_error())
+            return False
+        if all_agree(lib.m3l_comm_world() == self.world):      # a live communicator of this process (an earlier GradSync): shared
+            return True
         ident = C.create_string_buffer(128)
         ok = 1
         if rank == 0:
@@ -144,20 +166,30 @@ class GradSync:
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         if box[0] is None:
-            warnings.warn("m3l_amd: RCCL not available to the library (%s); gradient all-reduce through torch.distributed" % L.last_error())
+            warnings.warn("m3l_amd: ncclGetUniqueId failed on rank 0 (%s); gradient all-reduce through torch.distributed" % L.last_error())
             return False
         with torch.cuda.device(dev):
             rc = lib.m3l_comm_init(C.create_string_buffer(box[0], 128), rank, self.world)
-        flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
-        if self.world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)        # all ranks take the same path
-        if float(flag.item()) < 1.0:
-            warnings.warn("m3l_amd: m3l_comm_init failed (%s); gradient all-reduce through torch.distributed" % L.last_error())
-            return False
+        # (2) ncclCommInitRank either succeeds on every rank or the job cannot go on: a rank that failed here has left its peers with a
+        # communicator that will never complete a collective, so there is no safe fallback — every rank raises (the process exits non-zero)
+        if not all_agree(rc == 0):
+            lib.m3l_comm_destroy()
+            raise RuntimeError("m3l_amd: m3l_comm_init failed on at least one rank (%s): the ranks disagree about the RCCL communicator; "
+                               "set M3L_COMM=c10d to run the gradient all-reduce through torch.distributed" % L.last_error())
+        # (3) direct evidence that the communicator spans the ranks: sum of (rank + 1) over the library's own all-reduce
+        probe = torch.tensor([float(rank + 1)], device=dev)
+        L.check(lib.m3l_comm_allreduce(probe.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), "m3l_comm_allreduce (probe)")
+        L.check(lib.m3l_side_join(torch.cuda.current_stream().cuda_stream), "m3l_side_join")
+        want = self.world * (self.world + 1) / 2
+        if float(probe.item()) != want:
+            raise RuntimeError(f"m3l_amd: RCCL probe all-reduce returned {float(probe.item())}, expected {want} for {self.world} ranks")
+        self.rccl_probe = float(probe.item())
         return True
 
     def zero_grad(self):
         self.flat.zero_()
+        self._unscaled = False
+        self._pending_scale = 1.0
         self._reduced = set()
         self._written = set()
         self._ready, self._sent_end = [], 0
@@ -175,6 +207,7 @@ class GradSync:
                 if a <= end < b:
                     end, grew = b, True
         if end > self._sent_end and (flush or end - self._sent_end >= self.min_bucket_elems or end == self.flat.numel()):
+            self._unscaled = True
             if self._direct:
                 # in place, on the library's side stream: behind the compute stream's work so far (event) and behind the weight gradients
                 # already queued there; finish() joins the side stream before the optimizer reads the sums
@@ -223,9 +256,11 @@ class GradSync:
             return
         self._span_ready(min(a for a, _ in spans), max(b for _, b in spans))
 
-    def finish(self):
+    def finish(self, defer_scale: bool = False):
         """Send whatever has not travelled yet (buckets nobody reported: modules whose gradients come from several Functions),
-        then make the compute stream wait for every outstanding all-reduce (call before optimizer.step())."""
+        then make the compute stream wait for every outstanding all-reduce (call before optimizer.step()).  Idempotent: the 1 / world
+        scale is applied once per set of collectives.  defer_scale=True leaves the sums in the buffer and hands 1 / world to the
+        optimizer (FlatAdam.step folds it into its one launch: take_scale())."""
         if self._comm:
             for b in self._bucket_ids:
                 if b not in self._reduced:
@@ -238,9 +273,21 @@ class GradSync:
             self._keep.clear()
         for w in self._works:
             w.wait()
-        if (self._works or self._direct) and self.world > 1:
-            self.flat.mul_(1.0 / self.world)       # SUM then scale: works on every backend (gloo has no AVG)
         self._works = []
+        if self._unscaled and self.world > 1:      # SUM then scale: works on every backend (gloo has no AVG)
+            if defer_scale:
+                self._pending_scale *= 1.0 / self.world
+            else:
+                self.flat.mul_(1.0 / self.world)
+        self._unscaled = False
+        if not defer_scale and self._pending_scale != 1.0:     # an earlier deferred scale nobody consumed: apply it now
+            self.flat.mul_(self._pending_scale)
+            self._pending_scale = 1.0
+
+    def take_scale(self) -> float:
+        """The factor a finish(defer_scale=True) left for the optimizer (1.0 otherwise); consumed by the call."""
+        s, self._pending_scale = self._pending_scale, 1.0
+        return s
 
     def reduce_now(self):
         """Non-overlapped variant (used by tests / when hooks are not wanted)."""
@@ -270,7 +317,12 @@ class FlatAdam:
 
     def step(self):
         from . import _lib as L
-        if self.sync._keep:                      # a backward whose side-stream weight gradients have not been joined yet
+        if self.sync._keep or self.sync._unscaled:     # a backward whose side-stream work / collectives have not been joined yet
+            self.sync.finish(defer_scale=not self.capturable)
+        gscale = 1.0
+        if not self.capturable:
+            gscale = self.sync.take_scale()
+        elif self.sync._pending_scale != 1.0:
             self.sync.finish()
         g = self.param_groups[0]
         if self.capturable:
@@ -280,10 +332,10 @@ class FlatAdam:
                                               torch.cuda.current_stream().cuda_stream), "m3l_adam_step_dev")
             return
         self.step_count += 1
-        L.check(L.lib().m3l_adam_step(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                      self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
-                                      g["eps"], g["weight_decay"], self.step_count, torch.cuda.current_stream().cuda_stream),
-                "m3l_adam_step")
+        L.check(L.lib().m3l_adam_step_scaled(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                             g["eps"], g["weight_decay"], self.step_count, gscale, torch.cuda.current_stream().cuda_stream),
+                "m3l_adam_step_scaled")
 
     def state_dict(self):
         return {"step": int(self._step_dev.item()) if self.capturable else self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}

@@ -357,6 +357,14 @@ def run_vt_load(ref):
     out.update({"out/" + k: v.numpy() for k, v in o.items()})
     np.savez_compressed(os.path.join(HERE, "vt_load_u8.npz"), **out)
     print(f"vt_load_u8: keys={sorted(o.keys())} image dtype {o['image'].dtype}")
+    # ranges that are not representable in binary: lo is rounded to fp32 by `tensor - lo`, the span (hi - lo) is formed in Python
+    # double and rounded once by `tensor / span` (float(0.3) - float(0.1) != float(0.3 - 0.1) in fp32)
+    obs = {"image": g.random((2, 8, 8, 3), dtype=np.float32), "tactile": (g.random((2, 6, 4, 4), dtype=np.float32) * 2 - 1)}
+    o = pu.vt_load({k: v.copy() for k, v in obs.items()}, image_normalization=[0.1, 0.3], tactile_normalization=[-0.7, 0.9], frame_stack=1)
+    out = {"in/" + k: v for k, v in obs.items()}
+    out.update({"out/" + k: v.numpy() for k, v in o.items()})
+    np.savez_compressed(os.path.join(HERE, "vt_load_frac.npz"), **out)
+    print(f"vt_load_frac: keys={sorted(o.keys())}")
 
 
 def run_vtt_dino(num_register_tokens=0, name="vtt_dino_small", seed=21):

@@ -118,6 +118,30 @@ def test_cfg2_full_depth_vs_oracle(dt, mode):
         _check(CFG2, "cfg2", 16, dt, mode, 1e-2, 0.15, 2e-2)
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+def test_cfg2_full_depth_at_the_bench_kernel_selection(mode):
+    """The kernel variants bench.py times: at B = 128 the decoder is 128 tiles of 192 rows, so the library itself picks
+    mlp_t192_fwd<12,1,1> (out-proj prologue), mlp_t192_bwd<12,1>, attn_t192_fwd/bwd and qkv_bwd_t192 — the composition that runs at
+    B = 256 — and the encoder runs the one-launch stack; full depth 12 + 4, bf16, against the fp32 CPU oracle, same bounds as B = 16."""
+    lib = L.lib()
+    lib.m3l_prof_begin(None, 1)
+    try:
+        _check(CFG2, "cfg2_b128", 128, "bf16", mode, 1e-2, 0.15, 2e-2)
+    finally:
+        lib.m3l_prof_end()
+    import ctypes as C
+    kinds = set()
+    for i in range(lib.m3l_prof_count()):
+        name = C.create_string_buffer(96)
+        a, b, c_, d = C.c_double(), C.c_long(), C.c_double(), C.c_double()
+        lib.m3l_prof_get(i, name, 96, C.byref(a), C.byref(b), C.byref(c_), C.byref(d))
+        if b.value:
+            kinds.add(name.value.decode())
+    print("\n[fulldepth] kernel classes launched:", sorted(kinds))
+    for want in ("attn_tail_mlp_t192_fwd[24576x768x12]", "mlp_t192_bwd[24576x768x12]", "attn_t192_fwd[", "attn_t192_bwd[", "qkv_bwd_t192["):
+        assert any(k.startswith(want) for k in kinds), (want, sorted(kinds))
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_cfg4_full_depth_vs_oracle(dt):
     if dt == "fp32":

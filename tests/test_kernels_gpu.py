@@ -183,6 +183,12 @@ def test_vt_load_matches_golden(dev, golden_dir):
     out = vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, image_normalization=[0, 255], tactile_normalization=[-2, 3], frame_stack=2)
     for k, v in out.items():
         np.testing.assert_array_equal(v.cpu().numpy(), z["out/" + k])
+    # ranges that binary floats cannot represent ([0.1, 0.3], [-0.7, 0.9]): the span is formed in double and rounded once, as the
+    # reference's `tensor / (hi - lo)` does — fp32(0.3) - fp32(0.1) would be one ulp off
+    zf = np.load(os.path.join(golden_dir, "vt_load_frac.npz"))
+    outf = vt_load({"image": zf["in/image"], "tactile": zf["in/tactile"]}, image_normalization=[0.1, 0.3], tactile_normalization=[-0.7, 0.9])
+    for k, v in outf.items():
+        np.testing.assert_array_equal(v.cpu().numpy(), zf["out/" + k])
     # a path argument: .npz of arrays is accepted, the reference's pickled .npy is refused with an explanation
     import tempfile
     with tempfile.TemporaryDirectory() as d:

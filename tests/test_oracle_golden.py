@@ -140,6 +140,10 @@ def test_vt_load_uint8_and_ranges(golden_dir):
     out = O.vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, frame_stack=2, image_normalization=[0, 255], tactile_normalization=[-2, 3])
     for k, v in out.items():
         np.testing.assert_array_equal(v.numpy(), z["out/" + k])
+    z = _load(golden_dir, "vt_load_frac")          # ranges binary floats cannot represent: [0.1, 0.3] / [-0.7, 0.9]
+    out = O.vt_load({"image": z["in/image"], "tactile": z["in/tactile"]}, image_normalization=[0.1, 0.3], tactile_normalization=[-0.7, 0.9])
+    for k, v in out.items():
+        np.testing.assert_array_equal(v.numpy(), z["out/" + k])
 
 
 def test_sincos_buffers_match_reference_buffers(golden_dir):

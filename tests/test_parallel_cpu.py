@@ -59,7 +59,48 @@ def _worker(rank, world, port, ret):
     assert torch.allclose(sync.flat, torch.full_like(sync.flat, 1.5))
     # parameters see the reduced values through their .grad views
     assert float(mae.to_pixels.weight.grad[0, 0]) == 1.5
+    # finish() is idempotent: a second call, or a call with nothing sent since the last one, must not scale again
+    sync.zero_grad()
+    sync.flat.fill_(float(rank + 1))
+    sync.finish()
+    sync.finish()
+    ref = torch.full_like(sync.flat, float(rank + 1))
+    dist.all_reduce(ref)
+    ref.mul_(1.0 / world)
+    assert torch.equal(sync.flat, ref), (float(sync.flat[0]), float(ref[0]))
+    # deferred scale: the sums stay in the buffer, 1 / world is handed over exactly once (FlatAdam folds it into its launch)
+    sync.zero_grad()
+    sync.flat.fill_(float(rank + 1))
+    sync.finish(defer_scale=True)
+    assert torch.equal(sync.flat, torch.full_like(sync.flat, 3.0))
+    assert sync.take_scale() == 1.0 / world and sync.take_scale() == 1.0
+    sync.zero_grad()
+    sync.flat.fill_(float(rank + 1))
+    sync.finish(defer_scale=True)
+    sync.finish()                                    # nobody consumed the deferred factor: a plain finish() applies it
+    assert torch.equal(sync.flat, torch.full_like(sync.flat, 1.5)) and sync.take_scale() == 1.0
     ret[rank] = float(sync.flat.sum())
+    # learned position tables (use_sincosmod_encodings=False, pretrain_models.py:218-219,280-287): trained, trailing span of the buffer
+    torch.manual_seed(0)
+    enc2 = m3l_amd.VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128)
+    mae2 = m3l_amd.VTMAE(encoder=enc2, decoder_dim=64, decoder_depth=1, decoder_heads=2, use_sincosmod_encodings=False)
+    sync2 = GradSync(mae2)
+    n2 = dict(mae2.named_parameters())
+    pe, dpe = n2["encoder.pos_embedding"], n2["decoder_pos_emb.weight"]
+    assert pe.grad is not None and dpe.grad is not None
+    tail = sorted([sync2._span[id(pe)], sync2._span[id(dpe)]])
+    assert tail[0][1] == tail[1][0] and tail[1][1] == sync2.flat.numel(), tail          # the trailing span
+    assert sync2.buckets[-1][0] == tail[0][0] and 5 in sync2._bucket_ids
+    sync2.zero_grad()
+    for b in sync2._bucket_ids[:-1]:                 # the modules report their buckets; the position tables arrive through autograd
+        s_, e_, _ = sync2.buckets[sync2._bucket_ids.index(b)]
+        sync2.flat[s_:e_] = float(rank + 1)
+        sync2.bucket_done(b)
+    pe.grad.add_(float(rank + 1))                    # what AccumulateGrad does with the batch-summed token gradients
+    dpe.grad.add_(float(rank + 1))
+    sync2.finish()
+    assert torch.allclose(sync2.flat, torch.full_like(sync2.flat, 1.5))
+    assert float(pe.grad.flatten()[0]) == 1.5 and float(dpe.grad[0, 0]) == 1.5
     dist.destroy_process_group()
 
 

@@ -12,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from m3l_amd import VTMAE, VTT  # noqa: E402
+from m3l_amd import _lib as L  # noqa: E402
 from oracle import vtmae_oracle as O  # noqa: E402
 
 CASES = ["vt_small", "v_only_small", "vt_decdim", "vt_cfg2_geom", "vt_earlyconv", "vt_learnedpos"]
@@ -211,13 +212,16 @@ def test_cfg2_full_size_properties():
     assert all(torch.isfinite(p.grad).all() for p in mae.parameters() if p.grad is not None)
 
 
-def test_direct_grad_mode_matches_autograd_mode():
+@pytest.mark.parametrize("sincos", [True, False])
+def test_direct_grad_mode_matches_autograd_mode(sincos):
     """GradSync makes the kernels write parameter gradients straight into one flat buffer (no autograd accumulate):
-    the values must be bit-identical to the gradients autograd receives in the default mode."""
+    the values must be bit-identical to the gradients autograd receives in the default mode.  sincos=False: the learned position
+    tables (pretrain_models.py:218-219,280-287) own the trailing span of the buffer and receive their gradient through autograd."""
     from m3l_amd.parallel import GradSync
     torch.manual_seed(3)
     enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=128, depth=2, heads=2, mlp_dim=256)
-    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, compute_dtype="bf16").to(DEV)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, compute_dtype="bf16",
+                use_sincosmod_encodings=sincos).to(DEV)
     B = 5
     x = {"image": torch.rand(B, 3, 32, 32, device=DEV), "tactile1": torch.rand(B, 3, 16, 16, device=DEV),
          "tactile2": torch.rand(B, 3, 16, 16, device=DEV)}
@@ -226,7 +230,11 @@ def test_direct_grad_mode_matches_autograd_mode():
     ref = {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}
     mae.zero_grad(set_to_none=True)
     sync = GradSync(mae)
-    sync.flat.fill_(float("nan"))          # every slot must be overwritten by its producer
+    if sincos:
+        sync.flat.fill_(float("nan"))      # every slot must be overwritten by its producer
+    else:
+        sync.zero_grad()                   # (autograd ADDS the position-table gradients; the unused modality tables keep their zeros)
+        assert "encoder.pos_embedding" in ref and "decoder_pos_emb.weight" in ref
     mae(x, mask_noise=noises).backward()
     # without communication the tails of the transformer backwards are still un-joined on the side stream (recorded from the autograd
     # worker thread) and finish(), called from this thread, joins them
@@ -239,7 +247,7 @@ def test_direct_grad_mode_matches_autograd_mode():
         if n in ref:
             assert torch.equal(p.grad, ref[n]), n
         else:
-            assert p.grad is None, n
+            assert p.grad is None or (not sincos and not p.grad.any()), n
 
 
 @pytest.mark.parametrize("fixture", ["vtt_dino_small", "vtt_dino_reg"])
@@ -336,16 +344,16 @@ def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gt
     return mae
 
 
-@pytest.mark.parametrize("dt,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 1e-2, 0.15)])
-def test_reference_default_architecture(dt, tol, gtol):
-    """M3L's own defaults (train.py:58-67,128-153): dim 256 / depth 4 / heads 4 / mlp 512, decoder 256 / 3 / 4, mask 0.95,
-    early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row), at B = 3 and reduced depth; bf16 also takes the
-    4 x 4 im2col kernel of the EarlyCNN stem."""
-    cfg = O.OracleCfg(64, 32, 8, 4, 256, 2, 4, 512, 12, 2, 256, 1, 4, 0.95)
-    _parity_vs_oracle(dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=256, depth=2, heads=4, mlp_dim=512,
+@pytest.mark.parametrize("dt,tol,gtol,B", [("fp32", 1e-4, 3e-3, 3), ("bf16", 1e-2, 0.15, 3), ("bf16", 1e-2, 0.15, 40)])
+def test_reference_default_architecture(dt, tol, gtol, B):
+    """M3L's own defaults at their real depth (train.py:58-67,128-153): dim 256 / depth 4 / heads 4 / mlp 512, decoder 256 / depth 3 /
+    4 heads / mlp 1024, mask 0.95, early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row); bf16 also takes
+    the 4 x 4 im2col kernel of the EarlyCNN stem, and at B = 40 the decoder is M = 7680 rows (40 full row tiles)."""
+    cfg = O.OracleCfg(64, 32, 8, 4, 256, 4, 4, 512, 12, 2, 256, 3, 4, 0.95)
+    _parity_vs_oracle(dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=256, depth=4, heads=4, mlp_dim=512,
                            image_channels=12, tactile_channels=12, num_tactiles=2, frame_stack=4),
-                      dict(decoder_dim=256, masking_ratio=0.95, decoder_depth=1, decoder_heads=4, num_tactiles=2, early_conv_masking=True,
-                           frame_stack=4, compute_dtype=dt), B=3, C=12, hw_img=64, hw_tac=32, k=2, cfg=cfg, tol=tol, gtol=gtol)
+                      dict(decoder_dim=256, masking_ratio=0.95, decoder_depth=3, decoder_heads=4, num_tactiles=2, early_conv_masking=True,
+                           frame_stack=4, compute_dtype=dt), B=B, C=12, hw_img=64, hw_tac=32, k=2, cfg=cfg, tol=tol, gtol=gtol)
 
 
 def test_cfg4_shapes():
@@ -903,8 +911,15 @@ def test_gradsync_second_backward_accumulates():
     mae.zero_grad(set_to_none=True)
     sync = GradSync(mae)
     sync.zero_grad()
-    two_backwards()
+    mae(x, mask_noise=noises).backward()
+    # the first backward left weight gradients un-joined on the library's side stream (deferred join) ...
+    assert L.lib().m3l_side_pending() > 0
+    mae.get_embeddings(x, eval=False).square().mean().backward()
+    # ... and the second one, which accumulates into the same flat views through autograd, joined them first (no race
+    # between AccumulateGrad on the compute stream and the first backward's weight-gradient kernels on the side stream)
+    assert L.lib().m3l_side_pending() == 0
     sync.finish()
+    sync.finish()                                                 # idempotent
     for n, p in mae.named_parameters():
         if n in ref:
             assert torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-7), n

@@ -36,9 +36,18 @@ CFG2 = dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_si
 # --workload cfg4 for the multi-GPU ViT-Small measurement; the headline line (no flag) is always configs[1]
 CFG4 = dict(image_size=224, tactile_size=64, image_patch_size=16, tactile_patch_size=8, dim=384, depth=12, heads=6, mlp_dim=1536,
             dec_dim=192, dec_depth=4, dec_heads=3, ratio=0.75, num_tactiles=4)
+# BASELINE configs[4]'s MAE (train_dino_cat_mae.py:76,78,138-160: 70x70 frames, P = 14, frame_stack 4 -> 12 channels, 384/4/4/768, decoder
+# 384/3/4, mask 0.8) and M3L's own default architecture (train.py:58-67,128-153: 256/4/4/512, decoder 256/3/4, early_conv_masking=True,
+# frame_stack 4, mask 0.95): not headline workloads — timed briefly after the headline run and reported under "secondary"
+CFG5 = dict(image_size=70, tactile_size=70, image_patch_size=14, tactile_patch_size=14, dim=384, depth=4, heads=4, mlp_dim=768,
+            dec_dim=384, dec_depth=3, dec_heads=4, ratio=0.8, num_tactiles=2, channels=12, frame_stack=4)
+CFGREF = dict(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=256, depth=4, heads=4, mlp_dim=512,
+              dec_dim=256, dec_depth=3, dec_heads=4, ratio=0.95, num_tactiles=2, channels=12, frame_stack=4, early_conv=True)
 WORKLOADS = {
     "cfg2": (CFG2, 256, "BASELINE configs[1]: VTT vision+tactile MAE, 64x64 RGB + 2x32x32 tactile, ViT-Tiny 192/12/3/768 + decoder 192/4/3/768, mask 0.75"),
     "cfg4": (CFG4, 64, "BASELINE configs[3]: 224x224 RGB + 4x64x64 tactile, ViT-Small 384/12/6/1536 + decoder 192/4/3/768, mask 0.75"),
+    "cfg5": (CFG5, 128, "BASELINE configs[4] MAE: 3 x 70x70 frames x frame_stack 4, P14, 384/4/4/768 + decoder 384/3/4/1536, mask 0.8"),
+    "ref": (CFGREF, 512, "M3L default architecture (train.py:58-67,128-153): 256/4/4/512 + decoder 256/3/4/1024, EarlyCNN stems, frame_stack 4, mask 0.95"),
 }
 
 
@@ -54,9 +63,21 @@ def fwd_flops_per_sample(c):
     nm_img = int(nmask * (n_img / N))
     nm_tac = (nmask - nm_img) // k
     nvis = N - nm_img - k * nm_tac
-    pd_i, pd_t = 3 * c["image_patch_size"] ** 2, 3 * c["tactile_patch_size"] ** 2
+    ch = c.get("channels", 3)
+    pd_i, pd_t = ch * c["image_patch_size"] ** 2, ch * c["tactile_patch_size"] ** 2
     embed = 2 * (n_img - nm_img) * pd_i * c["dim"] + 2 * k * (n_tac - nm_tac) * pd_t * c["dim"]
     heads = 2 * nm_img * c["dec_dim"] * pd_i + 2 * k * nm_tac * c["dec_dim"] * pd_t
+    if c.get("early_conv"):      # EarlyCNN stems over whole frames (pretrain_models.py:37-56) and the loss over ALL patches (:311-322)
+        def stem(hw, tactile):
+            D, f, ci, tot = c["dim"], 0, ch, 0
+            for l, co in enumerate((D // 8, D // 4, D // 2, D)):
+                kh, st_, pad = (1, 1, 0) if l == 3 else ((3, 1, 1) if (l == 2 and tactile) else (4, 2, 1))
+                hw = (hw + 2 * pad - kh) // st_ + 1
+                tot += 2 * hw * hw * ci * kh * kh * co
+                ci = co
+            return tot
+        embed = stem(c["image_size"], False) + k * stem(c["tactile_size"], True)
+        heads = 2 * n_img * c["dec_dim"] * pd_i + 2 * k * n_tac * c["dec_dim"] * pd_t
     return embed + tf(nvis, c["dim"], c["depth"], c["heads"], c["mlp_dim"]) + tf(N, c["dec_dim"], c["dec_depth"], c["dec_heads"], 4 * c["dec_dim"]) + heads
 
 
@@ -74,12 +95,57 @@ def attn_gemm_fwd_flops_per_sample(c):
 def build_model(c, dtype, device):
     from m3l_amd import VTMAE, VTT
     torch.manual_seed(0)
+    ch, fs = c.get("channels", 3), c.get("frame_stack", 1)
     enc = VTT(image_size=c["image_size"], tactile_size=c["tactile_size"], image_patch_size=c["image_patch_size"],
               tactile_patch_size=c["tactile_patch_size"], dim=c["dim"], depth=c["depth"], heads=c["heads"], mlp_dim=c["mlp_dim"],
-              num_tactiles=c["num_tactiles"])
+              num_tactiles=c["num_tactiles"], image_channels=ch, tactile_channels=ch, frame_stack=fs)
     mae = VTMAE(encoder=enc, decoder_dim=c["dec_dim"], masking_ratio=c["ratio"], decoder_depth=c["dec_depth"],
-                decoder_heads=c["dec_heads"], num_tactiles=c["num_tactiles"], compute_dtype=dtype)
+                decoder_heads=c["dec_heads"], num_tactiles=c["num_tactiles"], compute_dtype=dtype,
+                early_conv_masking=c.get("early_conv", False), frame_stack=fs)
     return mae.to(device)
+
+
+def synthetic_batch(c, B, device, generator=None):
+    ch = c.get("channels", 3)
+    x = {"image": torch.rand(B, ch, c["image_size"], c["image_size"], device=device, generator=generator)}
+    for i in range(c["num_tactiles"]):
+        x[f"tactile{i + 1}"] = torch.rand(B, ch, c["tactile_size"], c["tactile_size"], device=device, generator=generator)
+    return x
+
+
+def secondary_workloads(dtype, dev, names=("cfg4", "cfg5", "ref"), steps=10, warmup=5):
+    """Short driver-timed runs of the other architectures (same step: zero_grad + mask + fwd + bwd + Adam), one GPU, after the headline
+    measurement: samples/s and ms/step each.  They make DESIGN.md section 5's secondary figures checkable in the driver's own run."""
+    from m3l_amd.parallel import FlatAdam, GradSync
+    rows = {}
+    for name in names:
+        c, B, desc = WORKLOADS[name]
+        mae = build_model(c, dtype, dev)
+        sync = GradSync(mae)
+        opt = FlatAdam(sync, lr=1e-4)
+        x = synthetic_batch(c, B, dev)
+
+        def step():
+            sync.zero_grad()
+            loss = mae(x)
+            loss.backward()
+            sync.finish(defer_scale=True)
+            opt.step()
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rows[name] = {"workload": desc, "batch": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+                      "samples_per_s": round(B * steps / el, 1), "model_tflops": round(3 * fwd_flops_per_sample(c) * B * steps / el / 1e12, 1),
+                      "loss": round(float(loss.detach()), 5)}
+        del mae, sync, opt, x
+        torch.cuda.empty_cache()
+    return rows
 
 
 CFG1 = dict(CFG2, num_tactiles=0)     # BASELINE configs[0]: vision-only MAE, 64x64 RGB, ViT-Tiny, mask 75 %, batch 8 on CPU
@@ -179,6 +245,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's default (256 for cfg2)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary-workload runs (cfg 4, cfg 5 MAE, reference default)")
     ap.add_argument("--roofline-kernel", default="wgrad[", help="kernel class event-timed inside the timed region ('' = every tracked class, diagnostic)")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: time fwd+bwd without the Adam update")
     args = ap.parse_args()
@@ -223,9 +290,7 @@ def main():
     opt = FlatAdam(sync, lr=1e-4)                 # torch.optim.Adam semantics, one HIP launch over the flat buffers
     B = args.batch
     torch.manual_seed(1234 + rank)
-    x = {"image": torch.rand(B, 3, c["image_size"], c["image_size"], device=dev)}
-    for i in range(c["num_tactiles"]):
-        x[f"tactile{i + 1}"] = torch.rand(B, 3, c["tactile_size"], c["tactile_size"], device=dev)
+    x = synthetic_batch(c, B, dev)
 
     def step():
         sync.zero_grad()
@@ -366,6 +431,8 @@ def main():
         # SURVEY 8d) at this sample rate over the dense bf16 MFMA peak of the GPUs used
         attn = 3 * attn_gemm_fwd_flops_per_sample(c) * value
         out["attention_gemm"] = {"tflops": round(attn / 1e12, 2), "frac_of_bf16_peak": round(attn / (world * PEAK_BF16_TFLOPS * 1e12), 5)}
+        if world == 1 and not args.no_secondary and args.workload == "cfg2":
+            out["secondary"] = secondary_workloads(args.dtype, dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

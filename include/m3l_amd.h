@@ -176,6 +176,38 @@ int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int 
 int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int nmask, int nm_img, const int64_t* masked,
                        const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream);
 
+/* ---- the whole MAE step in two calls: VTMAE.forward + loss.backward() (models/pretrain_models.py:146-342 as called at
+ * models/ppo_mae.py:262-263, models/sac_mae.py:284-291) for early_conv_masking=False, use_sincosmod_encodings=True.  The module entry
+ * points above chained in C: same kernels, launch order and results (bit-identical), two host calls instead of ten autograd hops.
+ * tensors / grads: ONE array, the groups in this order — embed (15, as m3l_embed_fwd) | encoder transformer (11 * depth + 2) |
+ * glue (6, as m3l_unshuffle_fwd) | decoder transformer (11 * depth + 2) | heads (4): m3l_mae_step_num_tensors() entries.
+ * noise: one (B, n_i) f32 array per present modality, RNG order image, tactile1..k (m3l_mask_sample).  ws: m3l_mae_step_ws_bytes, holds
+ * every activation between the two calls.  masked_out / unmasked_out (optional): int64 (B, num_masked) / (B, num_unmasked). */
+typedef struct m3l_mae_cfg {
+    m3l_geom geom;
+    m3l_tf_cfg enc, dec;
+    double masking_ratio;
+} m3l_mae_cfg;
+/* Data-parallel plan of m3l_mae_step_bwd (NULL = one rank): `flat` is the flat fp32 gradient buffer of `total` elements that the
+ * grads pointers point into, laid out in backward order; stage_end[i] = end of the prefix of it that is final after stage i — stages:
+ * heads, decoder chunks (top-down, layers_per_chunk layers each; one stage when layers_per_chunk is 0 or >= depth), glue, encoder
+ * chunks, embed.  Once the finished-but-unsent prefix holds >= min_bucket elements (or reaches total) it is summed over the ranks by
+ * m3l_comm_allreduce on the side stream.  *sent_out (optional) = elements sent; the caller sends any rest and joins (m3l_side_join). */
+typedef struct m3l_comm_plan {
+    float* flat;
+    long total, min_bucket;
+    int layers_per_chunk, n_stages;
+    const long* stage_end;
+    long* sent_out;
+} m3l_comm_plan;
+int m3l_mae_step_num_tensors(const m3l_mae_cfg* c);
+size_t m3l_mae_step_ws_bytes(const m3l_mae_cfg* c, int B);
+int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const float* const* noise,
+                     const void* const* tensors, void* ws, float* loss, int64_t* masked_out, int64_t* unmasked_out, void* stream);
+/* dloss: device f32 scalar (upstream gradient) or NULL for 1.  grads[i]: f32, shape of tensors[i], NULL = not wanted / no gradient. */
+int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const void* const* tensors, void* ws,
+                     const float* dloss, float* const* grads, const m3l_comm_plan* comm, void* stream);
+
 /* ---- EarlyCNN stem (early_conv_masking=True, the reference's default flag; pretrain_models.py:37-56,180-191): three
  * Conv2d+ReLU and a 1x1 Conv2d as im2col + MFMA GEMM.  srcs: nsrc NCHW f32 inputs of B samples each (the tactile sensors share
  * one stem; they are processed as one batch of nsrc*B).  tensors / grads: {conv1.w, conv1.b, ..., conv4.w, conv4.b}.

@@ -28,6 +28,15 @@ class TfCfg(C.Structure):
     _fields_ = [(n, c_i) for n in ("dim", "depth", "heads", "mlp_dim", "project_out", "dtype")]
 
 
+class MaeCfg(C.Structure):
+    _fields_ = [("geom", Geom), ("enc", TfCfg), ("dec", TfCfg), ("masking_ratio", C.c_double)]
+
+
+class CommPlan(C.Structure):
+    _fields_ = [("flat", c_p), ("total", C.c_long), ("min_bucket", C.c_long), ("layers_per_chunk", c_i), ("n_stages", c_i),
+                ("stage_end", C.POINTER(C.c_long)), ("sent_out", C.POINTER(C.c_long))]
+
+
 _SIGS = {
     "m3l_version": (c_i, []),
     "m3l_last_error": (c_i, [C.c_char_p, c_sz]),
@@ -71,6 +80,10 @@ _SIGS = {
     "m3l_heads_loss_fwd2": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                   c_p, c_p, c_p, c_p]),
     "m3l_heads_loss_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_mae_step_num_tensors": (c_i, [C.POINTER(MaeCfg)]),
+    "m3l_mae_step_ws_bytes": (c_sz, [C.POINTER(MaeCfg), c_i]),
+    "m3l_mae_step_fwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_mae_step_bwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(CommPlan), c_p]),
     "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
     "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

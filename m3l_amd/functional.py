@@ -386,6 +386,131 @@ class HeadsLossFn(torch.autograd.Function):
         return (None,) * 9 + (d_dec,) + _returned(sink, grads)
 
 
+# -------------------------------------------------------------------------------------------------------------------
+# The whole MAE step as ONE autograd node over two C calls (csrc/mae_step.hip): the module chain above runs inside the library.
+FUSED_STEP = True     # tests switch it off to compare against the per-module path (results are bit-identical)
+
+
+def _dev_ptrs(tensors, keep):
+    """void*[] of f32 device tensors; a tensor that is not f32-contiguous is converted and parked in `keep` (alive until backward)."""
+    arr = (L.c_p * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        if t is None:
+            continue
+        if t.dtype is not torch.float32 or not t.is_contiguous():
+            t = t.detach().contiguous().float()
+            keep.append(t)
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class StepPlan:
+    """Everything one fused step needs, assembled by VTMAE._step_fused: cfg (L.MaeCfg), the five tensor groups as one list, which of
+    them take a gradient in this call, the inputs and the GradSync (or None)."""
+    __slots__ = ("cfg", "tensors", "used", "image", "tactiles", "noises", "sync", "B", "nmask", "nvis", "ws", "keep", "versions", "tens_arr",
+                 "tac_arr")
+
+
+def _comm_plan(sync, plan, cfg):
+    """m3l_comm_plan for this model on `sync` (cached: the layout never changes): stage ends in the flat gradient buffer."""
+    key = (cfg.enc.depth, cfg.dec.depth, sync.layers_per_chunk, sync.min_bucket_elems)
+    cached = getattr(sync, "_step_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    groups = [15, 11 * cfg.enc.depth + 2, 6, 11 * cfg.dec.depth + 2, 4]
+    off = [0]
+    for n in groups:
+        off.append(off[-1] + n)
+    T = plan.tensors
+
+    def end_of(ts):
+        spans = [sync._span[id(t)] for t in ts if t is not None and id(t) in sync._span]
+        return max(b for _, b in spans) if spans else 0
+
+    def tf_ends(base, depth):
+        chunk = sync.layers_per_chunk
+        fin = T[base + 11 * depth: base + 11 * depth + 2]
+        if not chunk or chunk >= depth:
+            return [end_of(T[base: base + 11 * depth + 2])]
+        ends, hi = [], depth
+        while hi > 0:
+            lo = max(0, hi - chunk)
+            ends.append(end_of(T[base + 11 * lo: base + 11 * hi] + (fin if hi == depth else [])))
+            hi = lo
+        return ends
+    ends = [end_of(T[off[4]:off[5]])] + tf_ends(off[3], cfg.dec.depth) + [end_of(T[off[2]:off[3]])] + tf_ends(off[1], cfg.enc.depth) + [end_of(T[off[0]:off[1]])]
+    run = 0
+    for i, e in enumerate(ends):          # a stage with no parameters of its own (Identity enc_to_dec ...) keeps the previous prefix
+        run = max(run, e)
+        ends[i] = run
+    ends[-1] = sync.flat.numel()          # whatever is left (nothing, in the layouts GradSync builds) goes with the last stage
+    arr = (C.c_long * len(ends))(*ends)
+    sent = C.c_long(0)
+    cp = L.CommPlan(sync.flat.data_ptr(), sync.flat.numel(), sync.min_bucket_elems, int(sync.layers_per_chunk or 0), len(ends), arr, C.pointer(sent))
+    sync._step_plan = (key, (cp, arr, sent))
+    return sync._step_plan[1]
+
+
+class MaeStepFn(torch.autograd.Function):
+    """loss = VTMAE.forward(x) (models/pretrain_models.py:146-342) through m3l_mae_step_fwd / m3l_mae_step_bwd.  `tensors` are the
+    autograd inputs: every parameter of the step when autograd has to receive the gradients (no GradSync), or a single anchor parameter
+    when the kernels write the gradients straight into the GradSync's flat buffer."""
+
+    @staticmethod
+    def forward(ctx, plan, *tensors):
+        lib = L.lib()
+        dev = plan.image.device if plan.image is not None else plan.tactiles[0].device
+        cfg = plan.cfg
+        plan.keep = []
+        plan.ws = _ws(lib.m3l_mae_step_ws_bytes(C.byref(cfg), plan.B), dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        masked = torch.empty(plan.B, plan.nmask, dtype=torch.int64, device=dev)
+        unmasked = torch.empty(plan.B, plan.nvis, dtype=torch.int64, device=dev)
+        plan.tens_arr = _dev_ptrs(plan.tensors, plan.keep)
+        plan.tac_arr = L.ptr_array(plan.tactiles)
+        L.check(lib.m3l_mae_step_fwd(C.byref(cfg), plan.B, L.ptr(plan.image), plan.tac_arr, L.ptr_array(plan.noises), plan.tens_arr,
+                                     L.ptr(plan.ws), L.ptr(loss), L.ptr(masked), L.ptr(unmasked), _stream()), "m3l_mae_step_fwd")
+        plan.versions = _versions(plan.tensors)
+        plan.noises = None
+        ctx.plan = plan
+        ctx.n_in = len(tensors)
+        ctx.mark_non_differentiable(masked, unmasked)
+        return loss, masked, unmasked
+
+    @staticmethod
+    def backward(ctx, dloss, _dm, _du):
+        plan = ctx.plan
+        lib = L.lib()
+        for i, (t, v) in enumerate(zip(plan.tensors, plan.versions)):
+            if t is not None and t._version != v:
+                raise RuntimeError(f"MaeStepFn: parameter {i} was modified by an inplace operation between forward and backward "
+                                   f"(version {t._version}, expected {v})")
+        sync = plan.sync
+        grads, direct = _grad_targets((sync, None) if sync is not None else None, plan.tensors, plan.used)
+        dloss = _f32c(dloss)
+        comm = None
+        if direct and sync._comm:
+            comm = _comm_plan(sync, plan, plan.cfg)
+            comm[2].value = 0
+        defer = direct and sync._defer
+        if defer:
+            sync._keep.append((plan.ws, plan.keep, grads, dloss, plan.image, plan.tactiles))
+            lib.m3l_set_defer_join(1)
+        try:
+            L.check(lib.m3l_mae_step_bwd(C.byref(plan.cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws), L.ptr(dloss),
+                                         L.ptr_array(grads), C.byref(comm[0]) if comm is not None else None, _stream()), "m3l_mae_step_bwd")
+        finally:
+            if defer:
+                lib.m3l_set_defer_join(0)
+        if direct:
+            sync._reduced.update(sync._bucket_ids)
+            if comm is not None:
+                sync._sent_end = int(comm[2].value)
+                sync._unscaled = True
+            return (None,) * (1 + ctx.n_in)
+        return (None,) + tuple(g for g, t in zip(grads, plan.tensors) if t is not None)      # the autograd inputs = the non-None tensors
+
+
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim of an f32 tensor (final norm of the DINO-style encoder, models/VTT.py:354)."""
 

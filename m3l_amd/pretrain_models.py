@@ -304,8 +304,38 @@ class VTMAE(nn.Module):
                                 *self._embed_tensors(geom))
 
     # ------------------------------------------------------------------------------------------------------------
+    def _step_fused(self, image, tactiles, geom, mask_noise, c, B, sync):
+        """The whole step inside the library (csrc/mae_step.hip: m3l_mae_step_fwd / _bwd): one autograd node, two host calls."""
+        plan = Fn.StepPlan()
+        enc_tf, dec_tf = self.encoder.transformer, self.decoder
+        plan.cfg = L.MaeCfg(geom, enc_tf._cfg(), dec_tf._cfg(), float(self.masking_ratio))
+        emb, glue = self._embed_tensors(geom), self._glue_tensors(geom)
+        plan.tensors = emb + enc_tf._tensors() + glue + dec_tf._tensors() + self._head_tensors()
+        has_img, has_tac = image is not None, len(tactiles) > 0
+        # which tensors receive a gradient in this call (absent modalities and the fixed sincos tables do not)
+        plan.used = ([has_img] * 6 + [has_tac] * 6 + [True, False, False] + [True] * (11 * enc_tf.depth + 2) + [True, True, True, True, False, False]
+                     + [True] * (11 * dec_tf.depth + 2) + [has_img] * 2 + [has_tac] * 2)
+        for i, t in enumerate(plan.tensors):
+            if t is None or not t.requires_grad:
+                plan.used[i] = False
+        plan.image = Fn._f32c(image)
+        plan.tactiles = [Fn._f32c(t) for t in tactiles]
+        plan.noises = [Fn._f32c(n) for n in mask_noise]
+        plan.sync, plan.B, plan.nmask, plan.nvis = sync, B, c["num_masked"], c["num_unmasked"]
+        if sync is not None and torch.is_grad_enabled():
+            ins = (self.mask_token,)          # anchor: the kernels write every gradient in place, autograd only has to call backward
+        else:
+            ins = tuple(t for t in plan.tensors if t is not None)
+            for i, t in enumerate(plan.tensors):
+                if t is None:
+                    plan.used[i] = False
+        loss, masked, unmasked = Fn.MaeStepFn.apply(plan, *ins)
+        self.last_mask = (masked, unmasked)
+        return loss
+
     def _step(self, x, use_vision, use_tactile, mask_noise, dump, counts=None):
         image, tactiles, geom, ref = self._inputs(x, use_vision, use_tactile)
+        Fn._require_cuda(ref, "MAE input")
         B, dev = ref.shape[0], ref.device
         dt = Fn.dtype_code(self.compute_dtype)
         c = Fn.mask_counts(geom, self.masking_ratio)
@@ -313,6 +343,10 @@ class VTMAE(nn.Module):
         if mask_noise is None:
             mask_noise = [torch.rand(B, n, device=dev) for n in sizes]          # reference RNG order (:229,:237)
         assert [tuple(n.shape) for n in mask_noise] == [(B, n) for n in sizes], "mask_noise: one (B, n) tensor per modality"
+        sync = self._sinks["heads"][0] if "heads" in self._sinks else None
+        if (Fn.FUSED_STEP and dump is None and counts is None and not self.early_conv_masking and self.use_sincosmod_encodings
+                and Fn.BWD_CHUNK_LAYERS is None and (sync is None or not sync._comm or sync._direct)):
+            return self._step_fused(image, tactiles, geom, [n.to(dev) for n in mask_noise], c, B, sync)
         masked, unmasked, c = Fn.mask_sample(geom, self.masking_ratio, [n.to(dev) for n in mask_noise], counts)
         self.last_mask = (masked, unmasked)
         nvis_img = c["n_img"] - c["nm_img"]

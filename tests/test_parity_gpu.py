@@ -250,6 +250,77 @@ def test_direct_grad_mode_matches_autograd_mode(sincos):
             assert p.grad is None or (not sincos and not p.grad.any()), n
 
 
+@pytest.mark.parametrize("with_sync", [False, True])
+@pytest.mark.parametrize("arch", ["tiny_bf16", "decdim_bf16", "vision_only_fp32", "tiny_fp32"])
+def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
+    """csrc/mae_step.hip: the whole step as two library calls (one autograd node) against the five per-module autograd Functions —
+    same kernels in the same order, so loss, mask indices and every parameter gradient must be bit-identical; with a GradSync (the
+    kernels write the flat buffer, autograd sees one anchor input) and without (autograd receives every gradient)."""
+    from m3l_amd import functional as Fn
+    from m3l_amd.parallel import GradSync
+    kw = dict(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=128, depth=3, heads=2, mlp_dim=256)
+    mkw = dict(decoder_dim=128, masking_ratio=0.75, decoder_depth=2, decoder_heads=2)
+    if arch == "decdim_bf16":
+        mkw.update(decoder_dim=64, decoder_heads=1)          # enc_to_dec Linear + truncated decoder sincos
+    if arch == "vision_only_fp32":
+        kw.update(num_tactiles=0)
+        mkw.update(num_tactiles=0)
+    dt = "fp32" if arch.endswith("fp32") else "bf16"
+    B = 6
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = {"image": torch.rand(B, 3, 32, 32, generator=g).to(DEV)}
+    nt = kw.get("num_tactiles", 2)
+    for i in range(nt):
+        x[f"tactile{i + 1}"] = torch.rand(B, 3, 16, 16, generator=g).to(DEV)
+    noises = [torch.rand(B, 16, generator=g).to(DEV) for _ in range(1 + nt)]
+
+    def run(fused):
+        torch.manual_seed(2)
+        mae = VTMAE(encoder=VTT(**kw), compute_dtype=dt, **mkw).to(DEV)
+        sync = GradSync(mae) if with_sync else None
+        if sync is not None:
+            sync.zero_grad()
+        keep = Fn.FUSED_STEP
+        Fn.FUSED_STEP = fused
+        try:
+            loss = mae(x, mask_noise=noises)
+            assert (type(loss.grad_fn).__name__ == "MaeStepFnBackward") == fused
+            (loss * 1.5).backward()
+        finally:
+            Fn.FUSED_STEP = keep
+        if sync is not None:
+            sync.finish()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), mae.last_mask, {n: (None if p.grad is None else p.grad.clone()) for n, p in mae.named_parameters()}
+
+    l0, m0, g0 = run(False)
+    l1, m1, g1 = run(True)
+    assert torch.equal(l0, l1) and torch.equal(m0[0], m1[0]) and torch.equal(m0[1], m1[1])
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None), n
+        if g0[n] is not None:
+            assert torch.equal(g0[n], g1[n]), n
+    # use_vision / use_tactile flags go through the fused step too
+    if nt:
+        torch.manual_seed(2)
+        mae = VTMAE(encoder=VTT(**kw), compute_dtype=dt, **mkw).to(DEV)
+        res = []
+        for fused in (False, True):
+            Fn.FUSED_STEP = fused
+            try:
+                mae.zero_grad(set_to_none=True)
+                loss = mae(x, use_vision=False, mask_noise=noises[1:])
+                loss.backward()
+                res.append((loss.detach().clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in mae.named_parameters()}))
+            finally:
+                Fn.FUSED_STEP = True
+        assert torch.equal(res[0][0], res[1][0])
+        for n in res[0][1]:
+            a, b = res[0][1][n], res[1][1][n]
+            assert (a is None) == (b is None), n
+            assert a is None or torch.equal(a, b), n
+
+
 @pytest.mark.parametrize("fixture", ["vtt_dino_small", "vtt_dino_reg"])
 def test_dino_style_vtt_matches_reference_fixture(golden_dir, fixture):
     """models/VTT.py forward / forward_features (with and without keep-index masks; without and with 4 register tokens, :166-172,

@@ -5,7 +5,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 "$@" > $OUT/stats.log 2>&1
 cd $R
 F=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 cp $F $OUT/kernel_stats.csv

@@ -182,7 +182,8 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
  * tensors / grads: ONE array, the groups in this order — embed (15, as m3l_embed_fwd) | encoder transformer (11 * depth + 2) |
  * glue (6, as m3l_unshuffle_fwd) | decoder transformer (11 * depth + 2) | heads (4): m3l_mae_step_num_tensors() entries.
  * noise: one (B, n_i) f32 array per present modality, RNG order image, tactile1..k (m3l_mask_sample).  ws: m3l_mae_step_ws_bytes, holds
- * every activation between the two calls.  masked_out / unmasked_out (optional): int64 (B, num_masked) / (B, num_unmasked). */
+ * every activation between the two calls.  masked / unmasked (out of the forward, in of the backward; caller-owned, unchanged in
+ * between): int64 (B, num_masked) / (B, num_unmasked) index lists in the reference's order. */
 typedef struct m3l_mae_cfg {
     m3l_geom geom;
     m3l_tf_cfg enc, dec;
@@ -203,10 +204,11 @@ typedef struct m3l_comm_plan {
 int m3l_mae_step_num_tensors(const m3l_mae_cfg* c);
 size_t m3l_mae_step_ws_bytes(const m3l_mae_cfg* c, int B);
 int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const float* const* noise,
-                     const void* const* tensors, void* ws, float* loss, int64_t* masked_out, int64_t* unmasked_out, void* stream);
+                     const void* const* tensors, void* ws, float* loss, int64_t* masked, int64_t* unmasked, void* stream);
 /* dloss: device f32 scalar (upstream gradient) or NULL for 1.  grads[i]: f32, shape of tensors[i], NULL = not wanted / no gradient. */
-int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const void* const* tensors, void* ws,
-                     const float* dloss, float* const* grads, const m3l_comm_plan* comm, void* stream);
+int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const int64_t* masked,
+                     const int64_t* unmasked, const void* const* tensors, void* ws, const float* dloss, float* const* grads,
+                     const m3l_comm_plan* comm, void* stream);
 
 /* ---- EarlyCNN stem (early_conv_masking=True, the reference's default flag; pretrain_models.py:37-56,180-191): three
  * Conv2d+ReLU and a 1x1 Conv2d as im2col + MFMA GEMM.  srcs: nsrc NCHW f32 inputs of B samples each (the tactile sensors share

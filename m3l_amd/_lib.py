@@ -83,7 +83,7 @@ _SIGS = {
     "m3l_mae_step_num_tensors": (c_i, [C.POINTER(MaeCfg)]),
     "m3l_mae_step_ws_bytes": (c_sz, [C.POINTER(MaeCfg), c_i]),
     "m3l_mae_step_fwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "m3l_mae_step_bwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(CommPlan), c_p]),
+    "m3l_mae_step_bwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(CommPlan), c_p]),
     "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
     "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -158,29 +158,30 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
 int m3l_enc_mega_enabled(void);      // bit 1: forward (env M3L_ENC_MEGA, default 1)
 int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* const* layers, int count, float eps, hipStream_t st);
 unsigned long long* m3l_attn_phase_buffer(void);
-// row-tiled fused half layers for long sequences (t192.hip): 192 token rows per workgroup, any M
+// row-tiled fused half layers (t192.hip), bf16, model width D = 192 / 256 / 384: a workgroup owns 192 / 128 / 96 token rows, any M
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);
-int m3l_mlp_t192_fwd(int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
+int m3l_mlp_t192_fwd(int D, int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st);
-// LN1 + QKV + attention per sample for 48 < n <= 192 (the decoder): xn1, qkv, o, lse as the per-op kernels write them
+// LN1 + QKV + attention per sample for 48 < n <= 192 (D = 192 / 3 heads, D = 256 / 4 heads): xn1, qkv, o, lse as the per-op kernels write them
 int m3l_attn_t192_fwd_supported(int dtype, int D, int heads, int n, int B);
-int m3l_attn_t192_fwd(int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
+int m3l_attn_t192_fwd(int D, int B, int n, const float* x, const float* ln_w, const float* ln_b, const void* wqkv, float eps, void* xn1, void* qkv,
                       void* o, float* lse, hipStream_t st);
 // dO = dx1_t Wo + the whole attention backward of a sample -> dqkv (same support as the forward)
-int m3l_attn_t192_bwd(int B, int n, const void* dx1t, const void* qkv, const void* o, const float* lse, const void* woT, void* dqkv,
+int m3l_attn_t192_bwd(int D, int B, int n, const void* dx1t, const void* qkv, const void* o, const float* lse, const void* woT, void* dqkv,
                       hipStream_t st);
 int m3l_attn_tail_mlp_t192_supported(int dtype, int D, int HD, int mlp, int M);
-int m3l_attn_tail_mlp_t192_fwd(int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
+int m3l_attn_tail_mlp_t192_fwd(int D, int M, int mlp, const void* o, const float* x, const void* wo, const float* bo, const float* ln2_w,
                                const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,
                                const float* b2, void* u, void* h, float* xout, hipStream_t st);
 int m3l_mlp_t192_short(void);        // 1: use the row-tiled MLP kernels for short sequences too
-int m3l_mlp_t192_tiles(int M);      // partial rows written to cs_part [tiles][mlp] and ln_part [tiles][3 D]
-int m3l_mlp_t192_bwd(int M, int mlp, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u, const void* w2T,
+int m3l_mlp_t192_tiles(int D, int M);     // partial rows written to ln_part [tiles][3 D]
+int m3l_mlp_t192_cs_rows(int D, int M);   // partial rows written to cs_part [rows][mlp]: tiles (D = 192) or tiles x waves
+int m3l_mlp_t192_bwd(int D, int M, int mlp, const void* dxt, float* dx, const float* x1, const float* ln2_w, const void* u, const void* w2T,
                      const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st);
-// dxn1 = dqkv Wqkv + LN1 backward per 192-row tile (long sequences); ln_part [tiles][3 D]
+// dxn1 = dqkv Wqkv + LN1 backward per row tile; ln_part [tiles][3 D]
 int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M);
-int m3l_qkv_bwd_t192_tiles(int M);
-int m3l_qkv_bwd_t192(int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
+int m3l_qkv_bwd_t192_tiles(int D, int M);
+int m3l_qkv_bwd_t192(int D, int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
                      float* dx_out, void* dxt_out, float* ln_part, hipStream_t st);
 int m3l_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, hipStream_t st);
 int m3l_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int n,

@@ -286,8 +286,8 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.scratch_tn_b = m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * w.wg_batch);
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_tn_b));
-    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B), m3l_mlp_t192_tiles((int)M)) * mlp);   // B: one partial row per sample (block kernels)
-    w.ln_part_stride = (size_t)std::max(std::max(m3l_ln_bwd_blocks((int)M), B), m3l_mlp_t192_tiles((int)M)) * 3 * D;
+    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B), m3l_mlp_t192_cs_rows((int)D, (int)M)) * mlp);   // B: one partial row per sample (block kernels)
+    w.ln_part_stride = (size_t)std::max(std::max(m3l_ln_bwd_blocks((int)M), B), std::max(m3l_mlp_t192_tiles((int)D, (int)M), m3l_qkv_bwd_t192_tiles((int)D, (int)M))) * 3 * D;
     w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
     return w;
@@ -599,7 +599,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         const bool attn_t = !block && !fuse && c->project_out && m3l_attn_t192_fwd_supported(dt, D, c->heads, n, B);
         if (attn_t) {
             // long sequences: LN1 + QKV + attention of a sample in one launch (the out-proj + LN2 continue in the feed-forward launch)
-            if (m3l_attn_t192_fwd(B, n, x, ln1_w, ln1_b, L.wqkv, LN_EPS, L.xn1, L.qkv, L.o, L.lse, st)) return 1;
+            if (m3l_attn_t192_fwd(D, B, n, x, ln1_w, ln1_b, L.wqkv, LN_EPS, L.xn1, L.qkv, L.o, L.lse, st)) return 1;
         }
         if (!block && !attn_t && (!fuse || l == 0)) {
             if (m3l_ln_fwd(dt, x, M, D, ln1_w, ln1_b, LN_EPS, L.xn1, nullptr, st)) return 1;
@@ -613,7 +613,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         }
         if (c->project_out && !fuse && m3l_attn_tail_mlp_t192_supported(dt, D, HD, mlp, M)) {
             // long sequences: out-proj + residual + LN2 + fc1 + GELU + fc2 + residual in ONE launch per 192-row tile
-            if (m3l_attn_tail_mlp_t192_fwd(M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h,
+            if (m3l_attn_tail_mlp_t192_fwd(D, M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h,
                                            L.xout, st))
                 return 1;
             x = L.xout;
@@ -643,7 +643,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         }
         if (!fuse && m3l_mlp_t192_supported(dt, D, mlp, M)) {
             // long sequences: fc1 + GELU + fc2 + residual per 192-row tile, the hidden activation never leaves the CU between the GEMMs
-            if (m3l_mlp_t192_fwd(M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
+            if (m3l_mlp_t192_fwd(D, M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
             x = L.xout;
             continue;
         }
@@ -791,9 +791,9 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
                 return 1;
         } else if (mlp_t192) {
             // long sequences: the same chain per 192-row tile; one partial row per tile
-            cs_rows = m3l_mlp_t192_tiles(M);
-            if (m3l_mlp_t192_bwd(M, mlp, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
-                                 w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, cs_rows), st))
+            cs_rows = m3l_mlp_t192_cs_rows(D, M);
+            if (m3l_mlp_t192_bwd(D, M, mlp, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
+                                 w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, m3l_mlp_t192_tiles(D, M)), st))
                 return 1;
         } else {
         e.out_t = w.du[cur]; e.gelu_u = L.u; e.colsum_part = w.scratch2[cur];
@@ -833,7 +833,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         const bool attn_t = !attn_block && !fuse && c->project_out && m3l_attn_t192_fwd_supported(dt, D, c->heads, n, B);
         if (attn_t) {
             // long sequences: dO + both attention-backward passes of a sample in one launch
-            if (m3l_attn_t192_bwd(B, n, w.dx1_t[cur], L.qkv, L.o, L.lse, L.woT, w.dqkv[cur], st)) return 1;
+            if (m3l_attn_t192_bwd(D, B, n, w.dx1_t[cur], L.qkv, L.o, L.lse, L.woT, w.dqkv[cur], st)) return 1;
         }
         if (!attn_block && !attn_t) {
         if (c->project_out) {
@@ -870,8 +870,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         } else if (m3l_qkv_bwd_t192_supported(dt, D, 3 * HD, M)) {
             // long sequences: dxn1 and the LN1 backward per 192-row tile, dxn1 never leaves the registers
             if (l && claim_set(nxt)) return 2;
-            const int tiles = m3l_qkv_bwd_t192_tiles(M);
-            if (m3l_qkv_bwd_t192(M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
+            const int tiles = m3l_qkv_bwd_t192_tiles(D, M);
+            if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
                                  ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                 return 1;
         } else {

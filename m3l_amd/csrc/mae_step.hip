@@ -36,7 +36,6 @@ struct StepDims {
 };
 
 struct StepWs {
-    int64_t *masked, *unmasked;
     float *tokens, *enc32, *dec_in, *dec32, *d_dec_in, *dtokens;
     void *enc_t, *dec_t, *d_dec, *d_enc;
     void *ws_embed, *ws_enc, *ws_glue, *ws_dec, *ws_heads;
@@ -68,8 +67,6 @@ StepWs step_layout(const m3l_mae_cfg* c, const StepDims& d, int B, void* ws) {
     Arena a(ws);
     StepWs w;
     const size_t e = d.dt ? 2 : 4, Mv = (size_t)B * d.nvis, Ma = (size_t)B * d.N;
-    w.masked = (int64_t*)a.take((size_t)B * d.nmask * sizeof(int64_t));
-    w.unmasked = (int64_t*)a.take((size_t)B * d.nvis * sizeof(int64_t));
     w.tokens = (float*)a.take(Mv * d.D * 4);
     w.enc32 = (float*)a.take(Mv * d.D * 4);
     w.enc_t = d.dt ? a.take(Mv * d.D * e) : nullptr;
@@ -115,39 +112,38 @@ size_t m3l_mae_step_ws_bytes(const m3l_mae_cfg* c, int B) {
 }
 
 int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const float* const* noise,
-                     const void* const* tensors, void* ws, float* loss, int64_t* masked_out, int64_t* unmasked_out, void* stream) {
+                     const void* const* tensors, void* ws, float* loss, int64_t* masked, int64_t* unmasked, void* stream) {
     StepDims d;
-    M3L_CHECK(B > 0 && tensors && ws && loss && noise, "mae_step_fwd: null argument / B=%d", B);
+    M3L_CHECK(B > 0 && tensors && ws && loss && noise && masked && unmasked, "mae_step_fwd: null argument / B=%d", B);
     if (step_dims(c, &d)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const StepWs w = step_layout(c, d, B, ws);
     const Groups g = groups_of(c);
-    // mask sampling (pretrain_models.py:223-248) -> index lists in the workspace (the backward reads them again) + copies for the caller
-    if (m3l_mask_sample_counts(&c->geom, d.nm_img, d.nm_tac, B, noise, w.masked, w.unmasked, st)) return 1;
-    if (masked_out) M3L_HIP(hipMemcpyAsync(masked_out, w.masked, (size_t)B * d.nmask * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-    if (unmasked_out) M3L_HIP(hipMemcpyAsync(unmasked_out, w.unmasked, (size_t)B * d.nvis * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    // mask sampling (pretrain_models.py:223-248) -> the caller's index lists (the backward reads them again)
+    if (m3l_mask_sample_counts(&c->geom, d.nm_img, d.nm_tac, B, noise, masked, unmasked, st)) return 1;
     // patch embed of the visible tokens (:157-216,255-256)
-    if (m3l_embed_fwd(&c->geom, d.D, d.dt, B, d.nvis, d.nvis_img, w.unmasked, image, tactiles, tensors + g.embed, w.ws_embed, w.tokens, st)) return 1;
+    if (m3l_embed_fwd(&c->geom, d.D, d.dt, B, d.nvis, d.nvis_img, unmasked, image, tactiles, tensors + g.embed, w.ws_embed, w.tokens, st)) return 1;
     // encoder (:266)
     if (m3l_transformer_fwd(&c->enc, B, d.nvis, w.tokens, tensors + g.enc, w.ws_enc, w.enc_t, w.enc32, st)) return 1;
     // enc_to_dec + un-shuffle + decoder positions (:270-307); f32 compute: the "compute-type" encoder output is the f32 one
-    if (m3l_unshuffle_fwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, w.unmasked, w.masked, w.enc32, d.dt ? w.enc_t : (void*)w.enc32,
+    if (m3l_unshuffle_fwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, unmasked, masked, w.enc32, d.dt ? w.enc_t : (void*)w.enc32,
                           tensors + g.glue, w.ws_glue, w.dec_in, st))
         return 1;
     // decoder (:309)
     if (m3l_transformer_fwd(&c->dec, B, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.dec_t, w.dec32, st)) return 1;
     // heads + masked MSE (:260-262,327-340)
-    return m3l_heads_loss_fwd2(&c->geom, d.dd, d.dt, B, d.N, d.nmask, d.nm_img, w.masked, image, tactiles, d.dt ? w.dec_t : (void*)w.dec32,
+    return m3l_heads_loss_fwd2(&c->geom, d.dd, d.dt, B, d.N, d.nmask, d.nm_img, masked, image, tactiles, d.dt ? w.dec_t : (void*)w.dec32,
                                tensors + g.heads, w.ws_heads, loss, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 // Backward of the step.  grads: one f32 pointer per tensor (same order; NULL where the tensor has no gradient).  dloss: device scalar
 // or NULL (= 1).  comm (may be NULL = no communication): the flat gradient buffer and, per finished stage, the end of the prefix of it
 // that is final — heads, each decoder chunk (top-down), glue, each encoder chunk, embed — as GradSync lays it out.
-int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const void* const* tensors, void* ws,
-                     const float* dloss, float* const* grads, const m3l_comm_plan* comm, void* stream) {
+int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const int64_t* masked,
+                     const int64_t* unmasked, const void* const* tensors, void* ws, const float* dloss, float* const* grads,
+                     const m3l_comm_plan* comm, void* stream) {
     StepDims d;
-    M3L_CHECK(B > 0 && tensors && ws && grads, "mae_step_bwd: null argument / B=%d", B);
+    M3L_CHECK(B > 0 && tensors && ws && grads && masked && unmasked, "mae_step_bwd: null argument / B=%d", B);
     if (step_dims(c, &d)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const StepWs w = step_layout(c, d, B, ws);
@@ -182,18 +178,18 @@ int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const floa
         }
         return 0;
     };
-    if (m3l_heads_loss_bwd(&c->geom, d.dd, d.dt, B, d.N, d.nmask, d.nm_img, w.masked, tensors + g.heads, w.ws_heads, dloss, w.d_dec,
+    if (m3l_heads_loss_bwd(&c->geom, d.dd, d.dt, B, d.N, d.nmask, d.nm_img, masked, tensors + g.heads, w.ws_heads, dloss, w.d_dec,
                            grads + g.heads, st))
         return 1;
     if (stage_done()) return 1;
     if (tf_bwd(&c->dec, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.d_dec, d.dt, w.d_dec_in, grads + g.dec)) return 1;
     int enc_code = 0;
-    if (m3l_unshuffle_bwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, w.unmasked, w.masked, d.dt ? w.enc_t : (void*)w.enc32,
+    if (m3l_unshuffle_bwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, unmasked, masked, d.dt ? w.enc_t : (void*)w.enc32,
                           tensors + g.glue, w.ws_glue, w.d_dec_in, w.d_enc, &enc_code, grads + g.glue, st))
         return 1;
     if (stage_done()) return 1;
     if (tf_bwd(&c->enc, d.nvis, w.tokens, tensors + g.enc, w.ws_enc, w.d_enc, enc_code, w.dtokens, grads + g.enc)) return 1;
-    if (m3l_embed_bwd(&c->geom, d.D, d.dt, B, d.nvis, d.nvis_img, w.unmasked, image, tactiles, tensors + g.embed, w.ws_embed, w.dtokens,
+    if (m3l_embed_bwd(&c->geom, d.D, d.dt, B, d.nvis, d.nvis_img, unmasked, image, tactiles, tensors + g.embed, w.ws_embed, w.dtokens,
                       grads + g.embed, st))
         return 1;
     if (stage_done()) return 1;

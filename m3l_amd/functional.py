@@ -408,7 +408,7 @@ class StepPlan:
     """Everything one fused step needs, assembled by VTMAE._step_fused: cfg (L.MaeCfg), the five tensor groups as one list, which of
     them take a gradient in this call, the inputs and the GradSync (or None)."""
     __slots__ = ("cfg", "tensors", "used", "image", "tactiles", "noises", "sync", "B", "nmask", "nvis", "ws", "keep", "versions", "tens_arr",
-                 "tac_arr")
+                 "tac_arr", "masked", "unmasked")
 
 
 def _comm_plan(sync, plan, cfg):
@@ -464,21 +464,20 @@ class MaeStepFn(torch.autograd.Function):
         plan.keep = []
         plan.ws = _ws(lib.m3l_mae_step_ws_bytes(C.byref(cfg), plan.B), dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        masked = torch.empty(plan.B, plan.nmask, dtype=torch.int64, device=dev)
-        unmasked = torch.empty(plan.B, plan.nvis, dtype=torch.int64, device=dev)
+        plan.masked = torch.empty(plan.B, plan.nmask, dtype=torch.int64, device=dev)
+        plan.unmasked = torch.empty(plan.B, plan.nvis, dtype=torch.int64, device=dev)
         plan.tens_arr = _dev_ptrs(plan.tensors, plan.keep)
         plan.tac_arr = L.ptr_array(plan.tactiles)
         L.check(lib.m3l_mae_step_fwd(C.byref(cfg), plan.B, L.ptr(plan.image), plan.tac_arr, L.ptr_array(plan.noises), plan.tens_arr,
-                                     L.ptr(plan.ws), L.ptr(loss), L.ptr(masked), L.ptr(unmasked), _stream()), "m3l_mae_step_fwd")
+                                     L.ptr(plan.ws), L.ptr(loss), L.ptr(plan.masked), L.ptr(plan.unmasked), _stream()), "m3l_mae_step_fwd")
         plan.versions = _versions(plan.tensors)
         plan.noises = None
         ctx.plan = plan
         ctx.n_in = len(tensors)
-        ctx.mark_non_differentiable(masked, unmasked)
-        return loss, masked, unmasked
+        return loss
 
     @staticmethod
-    def backward(ctx, dloss, _dm, _du):
+    def backward(ctx, dloss):
         plan = ctx.plan
         lib = L.lib()
         for i, (t, v) in enumerate(zip(plan.tensors, plan.versions)):
@@ -497,7 +496,8 @@ class MaeStepFn(torch.autograd.Function):
             sync._keep.append((plan.ws, plan.keep, grads, dloss, plan.image, plan.tactiles))
             lib.m3l_set_defer_join(1)
         try:
-            L.check(lib.m3l_mae_step_bwd(C.byref(plan.cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws), L.ptr(dloss),
+            L.check(lib.m3l_mae_step_bwd(C.byref(plan.cfg), plan.B, L.ptr(plan.image), plan.tac_arr, L.ptr(plan.masked), L.ptr(plan.unmasked), plan.tens_arr,
+                                         L.ptr(plan.ws), L.ptr(dloss),
                                          L.ptr_array(grads), C.byref(comm[0]) if comm is not None else None, _stream()), "m3l_mae_step_bwd")
         finally:
             if defer:

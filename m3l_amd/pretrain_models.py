@@ -75,6 +75,7 @@ class Transformer(nn.Module):
         self.project_out = not (heads == 1 and dim_head == dim)
         self.compute_dtype = "fp32"
         self._sink = None            # (GradSync, bucket) when gradients go straight into a flat buffer (m3l_amd.parallel)
+        self._tcache = None          # the parameter list of _tensors() (the Parameter objects never change; dropped by _apply)
         self.norm = nn.LayerNorm(dim)
         self.layers = nn.ModuleList([])
         for _ in range(depth):
@@ -82,13 +83,19 @@ class Transformer(nn.Module):
                                               FeedForward(dim, mlp_dim, dropout=dropout)]))
 
     def _tensors(self):
-        t = []
-        for attn, ff in self.layers:
-            out = attn.to_out[0] if self.project_out else None
-            t += [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight,
-                  out.weight if out is not None else None, out.bias if out is not None else None,
-                  ff.net[0].weight, ff.net[0].bias, ff.net[1].weight, ff.net[1].bias, ff.net[4].weight, ff.net[4].bias]
-        return t + [self.norm.weight, self.norm.bias]
+        if self._tcache is None:
+            t = []
+            for attn, ff in self.layers:
+                out = attn.to_out[0] if self.project_out else None
+                t += [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight,
+                      out.weight if out is not None else None, out.bias if out is not None else None,
+                      ff.net[0].weight, ff.net[0].bias, ff.net[1].weight, ff.net[1].bias, ff.net[4].weight, ff.net[4].bias]
+            self._tcache = t + [self.norm.weight, self.norm.bias]
+        return list(self._tcache)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._tcache = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _cfg(self):
         return L.TfCfg(self.dim, self.depth, self.heads, self.mlp_dim, int(self.project_out), Fn.dtype_code(self.compute_dtype))
@@ -329,8 +336,8 @@ class VTMAE(nn.Module):
             for i, t in enumerate(plan.tensors):
                 if t is None:
                     plan.used[i] = False
-        loss, masked, unmasked = Fn.MaeStepFn.apply(plan, *ins)
-        self.last_mask = (masked, unmasked)
+        loss = Fn.MaeStepFn.apply(plan, *ins)
+        self.last_mask = (plan.masked, plan.unmasked)
         return loss
 
     def _step(self, x, use_vision, use_tactile, mask_noise, dump, counts=None):

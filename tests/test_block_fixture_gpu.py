@@ -95,16 +95,23 @@ def test_block_kernels_edge_lengths(D, heads, mlp, n, B):
         assert ey <= 5e-3 and edx <= 1e-2 and worst[1] <= 2e-2, (m, ey, edx, worst)
 
 
-@pytest.mark.parametrize("mlp,n,B", [(768, 192, 3), (768, 100, 3), (96, 64, 5), (384, 200, 2), (768, 48, 70), (768, 48, 130), (256, 20, 40), (768, 192, 210),
-                                     (768, 452, 64), (768, 100, 250), (768, 192, 129)])
-def test_t192_row_tiled_kernels(mlp, n, B):
-    """Long sequences (n > 48: the MAE decoder) run their half layers as 192-row tiles (t192.hip), whatever the sample boundaries: tiles
-    that straddle samples, a ragged last tile (M = B n not a multiple of 192) and a narrow MLP — against the fp32 oracle and against
-    the per-op bf16 kernels (M3L_T192 off), per parameter.  Modes: 3 = the library's own tile choice (<3,2> 48-row tiles below 128 tiles of
-    192 rows, <12,1> from there up: (768, 452, 64) is BASELINE cfg 4's decoder at B = 64, M = 28 928 = 150.67 tiles; (768, 100, 250) is
-    130.2 tiles; both end in a ragged <12,1> tile), 7 = every 192-row kernel (<12,1> MLP tiles, out-proj prologue, dxn1 + LN1 backward,
-    per-sample attention) forced at any M, so the small ragged shapes cover the <12,1> tail handling too."""
-    D, heads = 192, 3
+T192_CASES = [(192, 3, m, n, b) for m, n, b in [(768, 192, 3), (768, 100, 3), (96, 64, 5), (384, 200, 2), (768, 48, 70), (768, 48, 130), (256, 20, 40),
+                                                (768, 192, 210), (768, 452, 64), (768, 100, 250), (768, 192, 129)]]
+# widths 256 (M3L's default architecture: 256 / 4 heads, train.py:128-153) and 384 (ViT-Small: cfg 4's encoder 384 / 6 / 1536 at n = 113; cfg 5:
+# 384 / 4 heads -> inner width 256 != D, so no out-proj prologue): 128- / 96-row tiles, ragged last tiles, per-sample attention at D = 256
+T192_CASES += [(256, 4, 1024, 192, 3), (256, 4, 512, 10, 41), (256, 4, 1024, 192, 130), (256, 4, 1024, 100, 9), (384, 6, 1536, 113, 5),
+               (384, 4, 768, 75, 20), (384, 6, 1536, 113, 64), (384, 4, 1536, 15, 30)]
+
+
+@pytest.mark.parametrize("D,heads,mlp,n,B", T192_CASES)
+def test_t192_row_tiled_kernels(D, heads, mlp, n, B):
+    """Long sequences (n > 48: the MAE decoder) run their half layers as row tiles (t192.hip), whatever the sample boundaries: tiles
+    that straddle samples, a ragged last tile (M = B n not a multiple of the tile height) and a narrow MLP — against the fp32 oracle and
+    against the per-op bf16 kernels (M3L_T192 off), per parameter.  Modes: 3 = the library's own tile choice (D = 192: <3,2> 48-row tiles
+    below 128 tiles of 192 rows, <12,1> from there up: (768, 452, 64) is BASELINE cfg 4's decoder at B = 64, M = 28 928 = 150.67 tiles;
+    (768, 100, 250) is 130.2 tiles; both end in a ragged <12,1> tile.  D = 256 / 384: 128- / 96-row tiles from 1024 rows up), 7 = every
+    row-tiled kernel (MLP tiles, out-proj prologue, dxn1 + LN1 backward, per-sample attention) forced at any M, so the small ragged
+    shapes cover the tail handling too."""
     torch.manual_seed(n + mlp)
     tf = Transformer(D, 2, heads, 64, mlp)
     g = torch.Generator().manual_seed(n)
@@ -131,13 +138,13 @@ def test_t192_row_tiled_kernels(mlp, n, B):
         y, dx, grads = res[on]
         ey, edx = _relmax(y, yo.detach()), _relmax(dx, xo.grad)
         worst = max(((k, _relmax(gr, P["t." + k].grad)) for k, gr in grads.items()), key=lambda t: t[1])
-        print(f"\n[t192] mlp={mlp} n={n} t192={on} vs oracle: y {ey:.2e} dx {edx:.2e} worst {worst[0]} {worst[1]:.2e}")
+        print(f"\n[t192] D={D} mlp={mlp} n={n} B={B} t192={on} vs oracle: y {ey:.2e} dx {edx:.2e} worst {worst[0]} {worst[1]:.2e}")
         assert ey <= 5e-3 and edx <= 1e-2 and worst[1] <= 2e-2, (on, ey, edx, worst)
     y0, dx0, g0 = res[0]
     for on in (3, 7):
         y, dx, grads = res[on]
         worst = max(((k, _relmax(gr, g0[k])) for k, gr in grads.items()), key=lambda t: t[1])
-        print(f"\n[t192] mlp={mlp} n={n} t192={on} vs off: y {_relmax(y, y0):.2e} dx {_relmax(dx, dx0):.2e} worst {worst[0]} {worst[1]:.2e}")
+        print(f"\n[t192] D={D} mlp={mlp} n={n} B={B} t192={on} vs off: y {_relmax(y, y0):.2e} dx {_relmax(dx, dx0):.2e} worst {worst[0]} {worst[1]:.2e}")
         assert _relmax(y, y0) <= 5e-3 and _relmax(dx, dx0) <= 1e-2 and worst[1] <= 2e-2, on
 
 

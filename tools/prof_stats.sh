@@ -9,6 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- pytho
 cd $R
 F=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 cp $F $OUT/kernel_stats.csv
+[ -n "$KEEP_TRACE" ] || rm -rf $OUT/stats   # the kernel trace is tens of MB: gpurun merges at most 64 MiB back
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/kernel_stats.csv")))

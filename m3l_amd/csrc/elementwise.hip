@@ -217,22 +217,47 @@ __global__ __launch_bounds__(1024) void reduce_rows_batch_kernel(ReduceBatch b, 
     reduce_cols_32x32(it.part + (long)blockIdx.y * b.D, it.G, 3 * b.D, j, j < b.D, out, accumulate);
 }
 
-// column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, rows strided by grid
+// column sums of Y[M, N] (ld) -> part[G][N]; block = 256 threads, a block owns rows_per_block consecutive rows.  A thread owns 4 consecutive
+// columns (one 8- / 16-byte load per row instead of a 2-byte one: at the 2352-wide patches of cfg 5 the scalar version ran 45 us for
+// 36 MB) and keeps four independent row chains.
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16> { typedef bf16x4 type; };
+template <> struct Vec4<float> { typedef f32x4 type; };
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int M, int N, int ld, int rows_per_block,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, int vec_ok) {
+    typedef typename Vec4<T>::type V4;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent load -> add chains per thread
-        int r = r0;
-        for (; r + 3 < r1; r += 4) {
-            s0 += to_f32(Y[(long)r * ld + c]);
-            s1 += to_f32(Y[(long)(r + 1) * ld + c]);
-            s2 += to_f32(Y[(long)(r + 2) * ld + c]);
-            s3 += to_f32(Y[(long)(r + 3) * ld + c]);
+    for (int c = threadIdx.x * 4; c < N; c += 1024) {
+        if (vec_ok && c + 4 <= N) {
+            f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+            auto ld4 = [&](int r) {
+                const V4 v = *reinterpret_cast<const V4*>(Y + (long)r * ld + c);
+                return f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
+            };
+            int r = r0;
+            for (; r + 3 < r1; r += 4) {
+                s0 += ld4(r);
+                s1 += ld4(r + 1);
+                s2 += ld4(r + 2);
+                s3 += ld4(r + 3);
+            }
+            for (; r < r1; ++r) s0 += ld4(r);
+            *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * N + c) = (s0 + s1) + (s2 + s3);
+        } else {
+            for (int cc = c; cc < min(N, c + 4); ++cc) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent load -> add chains per thread
+                int r = r0;
+                for (; r + 3 < r1; r += 4) {
+                    s0 += to_f32(Y[(long)r * ld + cc]);
+                    s1 += to_f32(Y[(long)(r + 1) * ld + cc]);
+                    s2 += to_f32(Y[(long)(r + 2) * ld + cc]);
+                    s3 += to_f32(Y[(long)(r + 3) * ld + cc]);
+                }
+                for (; r < r1; ++r) s0 += to_f32(Y[(long)r * ld + cc]);
+                part[(long)blockIdx.x * N + cc] = (s0 + s1) + (s2 + s3);
+            }
         }
-        for (; r < r1; ++r) s0 += to_f32(Y[(long)r * ld + c]);
-        part[(long)blockIdx.x * N + c] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -266,11 +291,13 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(WeightPack pack) {
                 for (int j = 0; j < 4; ++j)
                     if (c + j < d.cols) v[j] = d.src[(long)r * d.cols + c + j];
             }
-            if (dst) {
+        }
+        // the copy is [ld_dstT rows][ld_dst cols]: the padding (zero-padded K of the patch / head / conv GEMMs; < 64 either way, so the
+        // tiles of the matrix cover it) is written here as zeros — no memset launches in front
+        if (dst && r < d.ld_dstT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c + j < d.cols) dst[(long)r * d.ld_dst + c + j] = from_f32<T>(v[j]);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (c + j < d.ld_dst) dst[(long)r * d.ld_dst + c + j] = from_f32<T>(v[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[p + 16 * k][4 * q + j] = v[j];
@@ -280,10 +307,10 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(WeightPack pack) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + p + 16 * k, r = r0 + 4 * q;
-        if (c >= d.cols) continue;
+        if (c >= d.ld_dst) continue;                 // transposed copy: [ld_dst rows][ld_dstT cols], padding zero
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (r + j < d.rows) dstT[(long)c * d.ld_dstT + r + j] = from_f32<T>(tile[4 * q + j][p + 16 * k]);
+            if (r + j < d.ld_dstT) dstT[(long)c * d.ld_dstT + r + j] = from_f32<T>(tile[4 * q + j][p + 16 * k]);
     }
 }
 
@@ -952,16 +979,30 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         int b, s, ph, pw, local;
         patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-        for (int t = lane; t < pdpad; t += 64) {
-            float d = 0.f;
-            int e = t;
-            if (t < pd) {
-                const float tv = patch_elem_t(pg, b, s, ph, pw, t, e);
-                d = pred[(long)row * pdpad + e] - tv;
-                if (target_out) target_out[(long)row * pd + e] = tv;
+        // four elements per lane in flight (loads first, then the stores: one element per iteration was a chain of dependent round
+        // trips, 119 us for the 7680 x 2352 patches of cfg 5); the per-lane sum keeps its order (t ascending)
+        for (int t0 = lane; t0 < pdpad; t0 += 256) {
+            float tv[4], pv[4];
+            int e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 64 * u;
+                e[u] = t;
+                tv[u] = pv[u] = 0.f;
+                if (t < pd) {
+                    tv[u] = patch_elem_t(pg, b, s, ph, pw, t, e[u]);
+                    pv[u] = pred[(long)row * pdpad + e[u]];
+                }
             }
-            acc += d * d;
-            dpred[(long)row * pdpad + e] = from_f32<T>(2.f * w * d);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 64 * u;
+                if (t >= pdpad) break;
+                const float d = t < pd ? pv[u] - tv[u] : 0.f;
+                if (t < pd && target_out) target_out[(long)row * pd + e[u]] = tv[u];
+                acc += d * d;
+                dpred[(long)row * pdpad + e[u]] = from_f32<T>(2.f * w * d);
+            }
         }
     }
     acc = wave_sum(acc);
@@ -1062,15 +1103,19 @@ int m3l_reduce_rows_seg3(const float* part, int G, int D, float* out0, float* ou
 
 int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st) {
     M3L_CHECK(M > 0 && N > 0, "colsum: bad shape");
-    int G = cdiv(M, 64);
+    // rows per block: 64 for narrow matrices (one pass of the 256 threads covers 1024 columns), 16 for wide ones so that the launch still
+    // has a few hundred blocks (7680 x 2352 at cfg 5: 120 blocks of 64 rows left half the CUs idle)
+    int G = cdiv(M, N > 512 ? 16 : 64);
     if (G > m3l_part_blocks()) G = m3l_part_blocks();
     const int rpb = cdiv(M, G);
     G = cdiv(M, rpb);
     ProfScope prof("colsum", M, N, dtype, (double)M * N * (dtype ? 2 : 4), st);
+    // vector path: 4-column pieces aligned in Y (ld and base) and in the partial rows (N)
+    const int vec_ok = (ld % 4 == 0) && (N % 4 == 0) && (((unsigned long)Y) % 16 == 0) && (((unsigned long)part_ws) % 16 == 0);
     if (dtype == 1)
-        colsum_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)Y, M, N, ld, rpb, part_ws);
+        colsum_kernel<bf16><<<G, 256, 0, st>>>((const bf16*)Y, M, N, ld, rpb, part_ws, vec_ok);
     else
-        colsum_kernel<float><<<G, 256, 0, st>>>((const float*)Y, M, N, ld, rpb, part_ws);
+        colsum_kernel<float><<<G, 256, 0, st>>>((const float*)Y, M, N, ld, rpb, part_ws, vec_ok);
     M3L_LAUNCH_CHECK();
     return m3l_reduce_rows(part_ws, G, N, N, out, accumulate, st);
 }
@@ -1081,8 +1126,11 @@ int m3l_prep_weights(int dtype, const WeightPack* pack_in, hipStream_t st) {
     WeightPack pack = *pack_in;
     int tiles = 0;
     for (int i = 0; i < pack.count; ++i) {
+        const WeightDesc& d = pack.d[i];
+        M3L_CHECK(d.ld_dst >= d.cols && d.ld_dstT >= d.rows && d.ld_dst <= ((d.cols + 63) / 64) * 64 && d.ld_dstT <= ((d.rows + 63) / 64) * 64,
+                  "prep_weights: padding of matrix %d ([%d, %d] -> [%d, %d]) must stay inside its last 64 x 64 tiles", i, d.rows, d.cols, d.ld_dstT, d.ld_dst);
         pack.tile0[i] = tiles;
-        tiles += ((pack.d[i].rows + 63) / 64) * ((pack.d[i].cols + 63) / 64);
+        tiles += ((d.rows + 63) / 64) * ((d.cols + 63) / 64);
     }
     pack.tile0[pack.count] = tiles;
     if (tiles == 0) return 0;

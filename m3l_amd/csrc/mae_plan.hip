@@ -129,6 +129,7 @@ struct Arena {
 };
 
 inline int pad8(int x) { return (x + 7) & ~7; }
+inline int pad64(int x) { return (x + 63) & ~63; }
 // LayerNorm forward / backward fused into the epilogue of the neighbouring GEMM (gemm_rowln.hip).  Correct (parity-tested) but
 // measured 2-3 % SLOWER than the separate kernels at cfg 2 on MI355X (a full-row tile caps the kernel at 2 workgroups per CU,
 // the stand-alone LayerNorm kernels run at 8 waves per SIMD), so it is off unless requested (M3L_ROWLN=1 / m3l_set_rowln).
@@ -167,8 +168,10 @@ Geo geo_of(const m3l_geom* g) {
     o.n_tac = o.k ? (g->tactile_h / g->tactile_patch) * (g->tactile_w / g->tactile_patch) : 0;
     o.pd_img = g->image_channels * g->image_patch * g->image_patch;
     o.pd_tac = g->tactile_channels * g->tactile_patch * g->tactile_patch;
-    o.pdp_img = pad8(o.pd_img);
-    o.pdp_tac = pad8(o.pd_tac);
+    // patch vectors are the K of the patch-embed GEMM and of the heads' dgrad: padded (zero columns) to the 64-element K tile of the
+    // LDS-DMA GEMM — K = 48 (cfg 2's tactile patches) and K = 2352 (cfg 5) took the generic kernel before
+    o.pdp_img = pad64(o.pd_img);
+    o.pdp_tac = pad64(o.pd_tac);
     return o;
 }
 PatchGroup group_img(const m3l_geom* g, const Geo& ge, const float* image) {
@@ -470,16 +473,11 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
     const int mod0[2] = {0, 1};
     SideSection side;
     if (!backward) {
-        // compute-type weight copies of both groups (zero-padded K) in ONE launch; pad columns must be zero (nothing to clear
-        // when there is no padding)
+        // compute-type weight copies of both groups in ONE launch (the zero padding of K is written by the same kernel)
         WeightPack pk;
         memset(&pk, 0, sizeof(pk));
         for (int i = 0; i < 2; ++i) {
             if (cnt[i] == 0) continue;
-            if (pdp[i] != pd[i]) {
-                M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)D * pdp[i] * esz(dtype), st));
-                M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)pdp[i] * D * esz(dtype), st));
-            }
             pk.d[pk.count++] = WeightDesc{(const float*)tensors[6 * i + 2], w.g[i].w, w.g[i].wT, D, pd[i], pdp[i], D};
         }
         if (m3l_prep_weights(dtype, &pk, st)) return 1;
@@ -1142,10 +1140,6 @@ int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int 
         memset(&pk, 0, sizeof(pk));
         for (int i = 0; i < 2; ++i) {
             if (cnt[i] == 0) continue;
-            if (pdp[i] != pd[i]) {
-                M3L_HIP(hipMemsetAsync(w.g[i].w, 0, (size_t)pdp[i] * dd * esz(dtype), st));
-                M3L_HIP(hipMemsetAsync(w.g[i].wT, 0, (size_t)dd * pdp[i] * esz(dtype), st));
-            }
             pk.d[pk.count++] = WeightDesc{(const float*)tensors[2 * i], w.g[i].w, w.g[i].wT, pd[i], dd, dd, pdp[i]};
         }
         if (m3l_prep_weights(dtype, &pk, st)) return 1;
@@ -1288,10 +1282,6 @@ int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* 
     CnnWs w = cnn_layout(c, Btot, ws);
     for (int l = 0; l < 4; ++l) {
         const ConvL& L = w.L[l];
-        if (L.Kpad != L.K) {
-            M3L_HIP(hipMemsetAsync(w.w[l], 0, (size_t)L.Co * L.Kpad * esz(dt), st));
-            M3L_HIP(hipMemsetAsync(w.wT[l], 0, (size_t)L.Kpad * L.Co * esz(dt), st));
-        }
         WeightPack pk;
         memset(&pk, 0, sizeof(pk));
         pk.d[0] = WeightDesc{(const float*)tensors[2 * l], w.w[l], w.wT[l], L.Co, L.K, L.Kpad, L.Co};

@@ -591,16 +591,29 @@ __device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, 
 // The t-th element of a patch in IMAGE order (c, p1, p2 with p2 fastest) and its patch-vector index e.  Kernels that walk a
 // patch with consecutive lanes use this order: P consecutive lanes read P consecutive pixels of one image row (one 4 P-byte
 // segment) instead of 64 lanes touching 64 different (channel, row) places; sums over the patch do not care about the order.
-__device__ __forceinline__ float patch_elem_t(const PatchGroup& pg, int b, int s, int ph, int pw, int t, int& e) {
-    const int pp = pg.P * pg.P;
-    const int c = t / pp, rem = t - c * pp, p1 = rem / pg.P, p2 = rem - p1 * pg.P;
+// t / d by one multiply: m = floor(2^32 / d) + 1 makes (t * m) >> 32 exact while t * d < 2^32 (here t < 2560, d <= 2560).  A patch
+// element otherwise costs two ~35-instruction integer divisions — at the 2352-wide patches of cfg 5 that arithmetic, not the memory,
+// set the time of the patch kernels (mse 104 us for 120 MB).
+struct PatchDiv {
+    unsigned m_pp, m_p;
+    int pp;
+};
+__device__ __forceinline__ PatchDiv patch_div(const PatchGroup& pg) {
+    PatchDiv d;
+    d.pp = pg.P * pg.P;
+    d.m_pp = 0xFFFFFFFFu / (unsigned)d.pp + 1u;
+    d.m_p = 0xFFFFFFFFu / (unsigned)pg.P + 1u;
+    return d;
+}
+__device__ __forceinline__ float patch_elem_t(const PatchGroup& pg, const PatchDiv& dv, int b, int s, int ph, int pw, int t, int& e) {
+    const int c = (int)__umulhi((unsigned)t, dv.m_pp), rem = t - c * dv.pp;
+    const int p1 = (int)__umulhi((unsigned)rem, dv.m_p), p2 = rem - p1 * pg.P;
     e = rem * pg.C + c;
     return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
 }
-__device__ __forceinline__ int patch_index_t(const PatchGroup& pg, int t) {
-    const int pp = pg.P * pg.P;
-    const int c = t / pp;
-    return (t - c * pp) * pg.C + c;
+__device__ __forceinline__ int patch_index_t(const PatchGroup& pg, const PatchDiv& dv, int t) {
+    const int c = (int)__umulhi((unsigned)t, dv.m_pp);
+    return (t - c * dv.pp) * pg.C + c;
 }
 
 // gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
@@ -612,6 +625,7 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int pd = pg.C * pg.P * pg.P;
+    const PatchDiv dv = patch_div(pg);
     int b, s, ph, pw, local;
     patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
     float v[NV];
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int6
     for (int i = 0; i < NV; ++i) {
         const int t = lane + 64 * i;
         ei[i] = t;
-        v[i] = (t < pd) ? patch_elem_t(pg, b, s, ph, pw, t, ei[i]) : 0.f;
+        v[i] = (t < pd) ? patch_elem_t(pg, dv, b, s, ph, pw, t, ei[i]) : 0.f;
         sum += v[i];
     }
     const float mean = wave_sum(sum) / pd;
@@ -651,6 +665,7 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
     __shared__ float red[WPB][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
+    const PatchDiv dv = patch_div(pg);
     float dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) dg[i] = db[i] = 0.f;
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         for (int i = 0; i < NV; ++i) {
             const int t = lane + 64 * i;
             ei[i] = t;
-            v[i] = (t < pd) ? patch_elem_t(pg, b, s, ph, pw, t, ei[i]) : 0.f;
+            v[i] = (t < pd) ? patch_elem_t(pg, dv, b, s, ph, pw, t, ei[i]) : 0.f;
             sum += v[i];
         }
         const float mean = wave_sum(sum) / pd;
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const 
         if (wave == 0) {
             const int t = lane + 64 * i;
             if (t < pd) {
-                const int e = patch_index_t(pg, t);
+                const int e = patch_index_t(pg, dv, t);
                 out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
                 out[pd + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
             }
@@ -975,6 +990,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     __shared__ float red[WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
+    const PatchDiv dv = patch_div(pg);
     float acc = 0.f;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         int b, s, ph, pw, local;
@@ -990,7 +1006,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
                 e[u] = t;
                 tv[u] = pv[u] = 0.f;
                 if (t < pd) {
-                    tv[u] = patch_elem_t(pg, b, s, ph, pw, t, e[u]);
+                    tv[u] = patch_elem_t(pg, dv, b, s, ph, pw, t, e[u]);
                     pv[u] = pred[(long)row * pdpad + e[u]];
                 }
             }

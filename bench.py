@@ -381,6 +381,7 @@ def main():
         # five more steps with every weight gradient on the compute stream (m3l_set_wgrad_inline) give the same kernel's duration when it
         # has the GPU to itself.
         kinds_alone = {}
+        family = {}
         if world == 1 and args.roofline_kernel and kinds:
             old_inline = lib.m3l_set_wgrad_inline(1)
             for _ in range(3):
@@ -392,25 +393,48 @@ def main():
             barrier()
             lib.m3l_prof_end()
             kinds_alone = prof_kinds()
+            # the whole weight-gradient family of a step (grouped launches, the small Linears' launches, the slab reduces): algorithmic
+            # bytes and slab bytes per step, to set beside the counter bytes of the same launches (profiles/*_traffic.json)
+            if args.roofline_kernel.startswith("wgrad"):
+                lib.m3l_prof_begin(b"wgrad", 1)
+                for _ in range(2):
+                    step()
+                barrier()
+                lib.m3l_prof_end()
+                family = {k: (v[1] / 2.0, v[3] / 2.0) for k, v in prof_kinds().items()}      # kind -> (launches, bytes) per step
             lib.m3l_set_wgrad_inline(old_inline)
         out["kernel_ms_sampled"] = {k: round(v[0] / args.steps, 4) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1][0])}
-        prof_json = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        prof = json.load(open(prof_json)) if os.path.exists(prof_json) else {}
+        import glob
+        prof_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+        prof_json = prof_files[-1] if prof_files else ""
+        prof_name = os.path.join("profiles", os.path.basename(prof_json)) if prof_json else None
+        prof = json.load(open(prof_json)) if prof_json else {}
         if kinds:
             kname, (ms_tot, launches, work, byt) = max(kinds.items(), key=lambda kv: kv[1][0])
             raw_us = ms_tot / launches * 1e3
             avg_s = max(raw_us - ev_overhead_us, 0.1) * 1e-6       # bracket minus the empty-bracket cost = kernel time
             gbs = byt / launches / avg_s / 1e9
             kfull = {"wgrad": "wgrad_kernel<3>", "gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname)
-            traffic = prof.get(kname, {}).get("hbm_bytes_per_launch")
+            traffic = prof.get("wgrad_grouped" if kname == "wgrad" else kname, prof.get(kname, {})).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": kfull, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(gbs / 8000.0, 4), "traffic": traffic,
-                               "traffic_source": "profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU lease (not re-measured in this run)" if traffic else None,
+                               "traffic_source": f"{prof_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU lease (not re-measured in this run), the same launch population as `achieved` (grouped launches only)" if traffic else None,
                                "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2),
                                "avg_bracket_us_raw": round(raw_us, 2), "event_bracket_overhead_us": round(ev_overhead_us, 2),
                                "launches_sampled": launches, "launches_per_step": round(launches * prof_stride / args.steps, 1),
                                "stand_alone": None,
                                "mfma_tflops": round(work / launches / avg_s / 1e12, 1), "mfma_frac_of_2500": round(work / launches / avg_s / 2.5e15, 4)}
+            if family:
+                # per step, like for like: counter bytes of every weight-gradient launch (kernel + slab reduce) against their algorithmic bytes
+                alg = sum(v[1] for k, v in family.items() if k in ("wgrad", "wgrad_small"))
+                slabs = sum(v[1] for k, v in family.items() if k == "wgrad_reduce")
+                fam = prof.get("wgrad_family_per_step", {})
+                pmc = fam.get("hbm_bytes_per_step")
+                out["roofline"]["per_step"] = {
+                    "launches": {k: v[0] for k, v in family.items()}, "algorithmic_bytes": round(alg), "split_m_slab_bytes": round(slabs),
+                    "pmc_bytes": pmc, "pmc_over_algorithmic": round(pmc / alg, 3) if pmc and alg else None,
+                    "note": "operands once + dW once (algorithmic) vs FETCH/WRITE counters of the same launches; the excess is the split-M slabs "
+                            "(written once, read once by the reduce kernels) and operand rows staged by more than one column tile"}
             if kname in kinds_alone:
                 a_ms, a_n, a_work, a_byt = kinds_alone[kname]
                 a_s = max(a_ms / a_n * 1e3 - ev_overhead_us, 0.1) * 1e-6
@@ -423,7 +447,7 @@ def main():
         if prof.get("_step"):
             sb = prof["_step"]["hbm_bytes_per_step"]
             out["step_hbm"] = {"bytes_per_step": sb, "GBps": round(sb / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(sb / (ms * 1e-3) / 8e12, 4),
-                               "source": "profiles/r02_traffic.json (PMC, builder's lease) / this run's ms_per_step"}
+                               "source": f"{prof_name} (PMC, builder's lease) / this run's ms_per_step"}
             out["top_kernels"] = prof["_step"].get("top_kernels")
         total_flops = 3 * fwd_flops_per_sample(c) * value
         out["model_tflops"] = round(total_flops / 1e12, 2)
@@ -431,6 +455,18 @@ def main():
         # SURVEY 8d) at this sample rate over the dense bf16 MFMA peak of the GPUs used
         attn = 3 * attn_gemm_fwd_flops_per_sample(c) * value
         out["attention_gemm"] = {"tflops": round(attn / 1e12, 2), "frac_of_bf16_peak": round(attn / (world * PEAK_BF16_TFLOPS * 1e12), 5)}
+        # BASELINE's ">= 40 % encoder-attention MFMA utilisation": measured per phase of the encoder's attention block by shader-clock
+        # stamps (tools/attn_phase_probe.py -> profiles/rNN_attn_phases.json, builder's lease), with the bound this problem size allows
+        ph_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_attn_phases.json")))
+        if ph_files:
+            ph = json.load(open(ph_files[-1]))
+            out["encoder_attention_mfma"] = {
+                "attention_phase_util": ph.get("phases", {}).get("attention", {}).get("mfma_util_issued"),
+                "attention_phase_util_useful_keys": ph.get("phases", {}).get("attention", {}).get("mfma_util_useful"),
+                "whole_attention_block_util": ph.get("kernel_mfma_util_useful"), "target": 0.40,
+                "bound": "~0.27 at the HBM roof: one encoder layer is 4.1 GFLOP (256 samples x 48 visible tokens) = 1.6 us at the bf16 peak, and with every "
+                         "activation saved for the backward the block moves ~86 FLOP per byte",
+                "source": os.path.join("profiles", os.path.basename(ph_files[-1])) + " (in-kernel shader-clock stamps, not re-measured in this run)"}
         if world == 1 and not args.no_secondary and args.workload == "cfg2":
             out["secondary"] = secondary_workloads(args.dtype, dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":

@@ -277,6 +277,20 @@ int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, in
 size_t m3l_op_gemm_tn_ws_bytes(int M, int N, int K);
 int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, void* ws, size_t ws_bytes,
                    float* out, int ldo, void* stream);
+/* building blocks of the trainable fusion MLP of the cfg-5 extractor (models/pretrain_models_dino_cat_mae.py:828-836,899-903: Linear + ReLU +
+ * Dropout x 2, Linear, over cat(pooled MAE tokens, DINOv2 feature)): column sums (bias gradients), compute-type + transposed weight copy
+ * (dst / dstT may be NULL), keep-mask / ReLU-mask scaling (mode 0: ref = uint8 mask; mode 1: ref = f32, on where ref > 0), and the
+ * (rows, na) | (rows, nb) concat (split = 0) / its adjoint (split = 1: a, b <- columns of cat; b may be NULL) */
+size_t m3l_op_colsum_ws_bytes(int N);
+int m3l_op_colsum(int dtype, const void* Y, int M, int N, int ld, void* ws, float* out, void* stream);
+int m3l_op_prep_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT, void* stream);
+int m3l_op_mask_scale(int mode, const float* src, const void* ref, float scale, long count, float* out, void* stream);
+int m3l_op_concat2(float* a, int na, float* b, int nb, int rows, float* cat, int split, void* stream);
+/* front end of the frozen image encoder (DINOv2 `patch_embed` + `prepare_tokens_with_masks`; models/pretrain_models_dino_cat_mae.py:886): patches
+ * of x (B, C, H, W) f32 as GEMM rows [B (H/P)(W/P), Kpad] in the Conv2d weight's K order; tokens = [cls + pos0 | registers | patch + pos] */
+int m3l_op_patch_cols(int dtype, const float* x, int B, int C, int H, int W, int P, int Kpad, void* col, void* stream);
+int m3l_op_vit_tokens(const float* emb, const float* cls, const float* regs, const float* pos, int B, int npatch, int R, int D, float* tok,
+                      void* stream);
 int m3l_op_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, void* stream);
 int m3l_op_attn_bwd(int dtype, const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv, int B,
                     int n, int H, void* stream);

@@ -109,6 +109,13 @@ _SIGS = {
     "m3l_op_gemm_nt": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "m3l_op_gemm_tn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "m3l_op_gemm_tn": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p, c_i, c_p]),
+    "m3l_op_colsum_ws_bytes": (c_sz, [c_i]),
+    "m3l_op_colsum": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "m3l_op_prep_weight": (c_i, [c_i, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "m3l_op_mask_scale": (c_i, [c_i, c_p, c_p, C.c_float, C.c_long, c_p, c_p]),
+    "m3l_op_concat2": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "m3l_op_patch_cols": (c_i, [c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "m3l_op_vit_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "m3l_op_attn_fwd": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "m3l_op_attn_bwd": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
 }

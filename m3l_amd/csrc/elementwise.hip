@@ -331,6 +331,41 @@ __global__ void scale_by_dev_kernel(const T* __restrict__ x, long count, const f
     if (i < count) out[i] = from_f32<T>(to_f32(x[i]) * s[0]);
 }
 
+// out = src * (ref "on" ? scale : 0): MODE 0 = ref is a uint8 keep-mask (nn.Dropout forward: scale = 1 / (1 - p)); MODE 1 = ref is the f32
+// OUTPUT of ReLU (+ Dropout) whose input gradient is wanted: on where ref > 0 (the fusion MLP of the cfg-5 extractor,
+// models/pretrain_models_dino_cat_mae.py:828-836)
+template <int MODE>
+__global__ void mask_scale_kernel(const float* __restrict__ src, const void* __restrict__ ref, float scale, long count, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const bool on = MODE == 0 ? reinterpret_cast<const uint8_t*>(ref)[i] != 0 : reinterpret_cast<const float*>(ref)[i] > 0.f;
+    out[i] = on ? src[i] * scale : 0.f;
+}
+// ViT token assembly of the frozen image encoder (DINOv2 prepare_tokens_with_masks; consumer: models/pretrain_models_dino_cat_mae.py:886):
+// tok[b, 0] = cls + pos[0];  tok[b, 1 .. R] = registers (no position);  tok[b, 1 + R + i] = emb[b, i] + pos[1 + i]
+__global__ void vit_tokens_kernel(const float* __restrict__ emb, const float* __restrict__ cls, const float* __restrict__ regs,
+                                  const float* __restrict__ pos, int B, int npatch, int R, int D, float* __restrict__ tok) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 1 + R + npatch;
+    if (i >= (long)B * n * D) return;
+    const int d = (int)(i % D), t = (int)((i / D) % n), b = (int)(i / ((long)D * n));
+    float v;
+    if (t == 0) v = cls[d] + pos[d];
+    else if (t <= R) v = regs[(long)(t - 1) * D + d];
+    else v = emb[((long)b * npatch + (t - 1 - R)) * D + d] + pos[(long)(t - R) * D + d];
+    tok[i] = v;
+}
+// dst[b, :] = a[b, 0 .. na) | b2[b, 0 .. nb)   (torch.cat((pooled, dino), dim=-1), :899) and its adjoint split
+__global__ void concat2_kernel(const float* __restrict__ a, int na, const float* __restrict__ b2, int nb, int rows, float* __restrict__ dst, int split) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = na + nb;
+    if (i >= (long)rows * w) return;
+    const int r = (int)(i / w), c = (int)(i % w);
+    if (!split) dst[i] = c < na ? a[(long)r * na + c] : b2[(long)r * nb + c - na];
+    else if (c < na) const_cast<float*>(a)[(long)r * na + c] = dst[i];
+    else if (b2) const_cast<float*>(b2)[(long)r * nb + c - na] = dst[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // EarlyCNN stem (pretrain_models.py:37-56) as im2col + MFMA GEMM.  K order = (ci, kh, kw) = the Conv2d weight layout, so
 // the weight / weight-gradient matrices need no permutation.  Activations between the convolutions are NHWC
@@ -1252,6 +1287,27 @@ int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_de
         scale_by_dev_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>((const bf16*)x, count, scale_dev, (bf16*)out);
     else
         scale_by_dev_kernel<float><<<cdiv(count, 256), 256, 0, st>>>((const float*)x, count, scale_dev, (float*)out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_mask_scale(int mode, const float* src, const void* ref, float scale, long count, float* out, hipStream_t st) {
+    M3L_CHECK((mode == 0 || mode == 1) && count > 0 && src && ref && out, "mask_scale: bad arguments");
+    if (mode == 0) mask_scale_kernel<0><<<cdiv(count, 256), 256, 0, st>>>(src, ref, scale, count, out);
+    else mask_scale_kernel<1><<<cdiv(count, 256), 256, 0, st>>>(src, ref, scale, count, out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+int m3l_vit_tokens(const float* emb, const float* cls, const float* regs, const float* pos, int B, int npatch, int R, int D, float* tok,
+                   hipStream_t st) {
+    M3L_CHECK(B > 0 && npatch > 0 && R >= 0 && D > 0 && emb && cls && pos && tok && (R == 0 || regs), "vit_tokens: bad arguments");
+    vit_tokens_kernel<<<cdiv((long)B * (1 + R + npatch) * D, 256), 256, 0, st>>>(emb, cls, regs, pos, B, npatch, R, D, tok);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+int m3l_concat2(float* a, int na, float* b2, int nb, int rows, float* cat, int split, hipStream_t st) {
+    M3L_CHECK(rows > 0 && na > 0 && nb > 0 && a && cat && (split || b2), "concat2: bad arguments");
+    concat2_kernel<<<cdiv((long)rows * (na + nb), 256), 256, 0, st>>>(a, na, b2, nb, rows, cat, split);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -199,6 +199,10 @@ int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
 int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
 int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
+int m3l_mask_scale(int mode, const float* src, const void* ref, float scale, long count, float* out, hipStream_t st);
+int m3l_vit_tokens(const float* emb, const float* cls, const float* regs, const float* pos, int B, int npatch, int R, int D, float* tok,
+                   hipStream_t st);
+int m3l_concat2(float* a, int na, float* b2, int nb, int rows, float* cat, int split, hipStream_t st);
 int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W, int C, float img_lo, float img_span, float* image_nchw,
                        const void* tactile, int tactile_u8, int th, int tw, int n_sensors, int frame_stack, float tac_lo, float tac_span,
                        float* const* tactile_out, hipStream_t st);

@@ -1424,6 +1424,37 @@ int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, in
                    float* out, int ldo, void* stream) {
     return m3l_gemm_tn(dtype, Y, ldy, X, ldx, M, N, K, (float*)ws, ws_bytes, out, ldo, N, K, 0, (hipStream_t)stream);
 }
+// ---- building blocks of the cfg-5 fusion head's trainable MLP (models/pretrain_models_dino_cat_mae.py:828-836,899-903) ----
+int m3l_op_colsum(int dtype, const void* Y, int M, int N, int ld, void* ws, float* out, void* stream) {
+    return m3l_colsum(dtype, Y, M, N, ld, (float*)ws, out, 0, (hipStream_t)stream);
+}
+size_t m3l_op_colsum_ws_bytes(int N) { return (size_t)M3L_MAX_PARTIAL_BLOCKS * N * sizeof(float) + 256; }
+int m3l_op_prep_weight(int dtype, const float* src, int rows, int cols, void* dst, void* dstT, void* stream) {
+    WeightPack pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.d[0] = WeightDesc{src, dst, dstT, rows, cols, cols, rows};
+    pk.count = 1;
+    return m3l_prep_weights(dtype, &pk, (hipStream_t)stream);
+}
+int m3l_op_mask_scale(int mode, const float* src, const void* ref, float scale, long count, float* out, void* stream) {
+    return m3l_mask_scale(mode, src, ref, scale, count, out, (hipStream_t)stream);
+}
+int m3l_op_concat2(float* a, int na, float* b, int nb, int rows, float* cat, int split, void* stream) {
+    return m3l_concat2(a, na, b, nb, rows, cat, split, (hipStream_t)stream);
+}
+// patch extraction of a P x P / stride-P patch-embed convolution (the frozen DINOv2's `patch_embed.proj`): x NCHW f32 -> col [B gh gw, Kpad]
+// in the Conv2d weight's K order (c, kh, kw), compute type, pad columns zero; and the encoder's token assembly
+int m3l_op_patch_cols(int dtype, const float* x, int B, int C, int H, int W, int P, int Kpad, void* col, void* stream) {
+    M3L_CHECK(x && col && B > 0 && P > 0 && H % P == 0 && W % P == 0 && Kpad >= C * P * P, "patch_cols: bad arguments");
+    ConvSrc cs;
+    memset(&cs, 0, sizeof(cs));
+    cs.src[0] = x; cs.nsrc = 1; cs.nchw = 1;
+    return m3l_im2col(dtype, &cs, B, C, H, W, P, P, 0, H / P, W / P, Kpad, col, (hipStream_t)stream);
+}
+int m3l_op_vit_tokens(const float* emb, const float* cls, const float* regs, const float* pos, int B, int npatch, int R, int D, float* tok,
+                      void* stream) {
+    return m3l_vit_tokens(emb, cls, regs, pos, B, npatch, R, D, tok, (hipStream_t)stream);
+}
 int m3l_op_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int B, int n, int H, void* stream) {
     return m3l_attn_fwd(dtype, qkv, o, lse, B, n, H, (hipStream_t)stream);
 }

@@ -148,17 +148,20 @@ class DinoV2Frozen(nn.Module):
         _, keep, ptrs, wp, pb, kp = self._prepare()
         dt = Fn.dtype_code(self.compute_dtype)
         T = Fn.tdtype(dt)
-        # patches in the Conv2d weight's K order (c, kh, kw); zero-padded to the GEMM's K
-        pt = x.float().reshape(B, Cc, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cc * P * P)
-        pt = F.pad(pt, (0, kp - pt.shape[1])).to(T).contiguous()
+        # patches in the Conv2d weight's K order (c, kh, kw), zero-padded to the GEMM's K: one HIP gather (m3l_op_patch_cols)
+        xf = x.detach().float().contiguous()
+        pt = torch.empty(B * gh * gw, kp, dtype=T, device=x.device)
+        L.check(L.lib().m3l_op_patch_cols(dt, L.ptr(xf), B, Cc, H, W, P, kp, L.ptr(pt), Fn._stream()), "m3l_op_patch_cols")
         emb = torch.empty(B * gh * gw, D, dtype=torch.float32, device=x.device)
         L.check(L.lib().m3l_op_gemm_nt(dt, L.ptr(pt), kp, L.ptr(wp), kp, B * gh * gw, D, kp, L.ptr(pb), None, L.ptr(emb), None, None,
                                        None, 0, D, Fn._stream()), "patch_embed")
         pos = self._pos(gh, gw)
         R = self.num_register_tokens
-        tok = torch.cat(((self.cls_token.float() + pos[:, :1]).expand(B, -1, -1), self.register_tokens.float().expand(B, -1, -1),
-                         emb.view(B, gh * gw, D) + pos[:, 1:]), dim=1).contiguous()
         n = 1 + R + gh * gw
+        tok = torch.empty(B, n, D, dtype=torch.float32, device=x.device)
+        cls, regs = self.cls_token.detach().float().contiguous(), self.register_tokens.detach().float().contiguous()
+        L.check(L.lib().m3l_op_vit_tokens(L.ptr(emb), L.ptr(cls), L.ptr(regs) if R else None, L.ptr(pos), B, gh * gw, R, D, L.ptr(tok), Fn._stream()),
+                "m3l_op_vit_tokens")
         cfg = L.TfCfg(D, self.depth, self.num_heads, self.mlp_dim, 1, dt)
         ws = Fn._ws(L.lib().m3l_frozen_vit_ws_bytes(C.byref(cfg), B, n), x.device)
         y = torch.empty(B, n, D, dtype=torch.float32, device=x.device)

@@ -634,3 +634,80 @@ class TokensAssembleFn(torch.autograd.Function):
                                                 _stream()), "m3l_tokens_assemble_bwd")
         _done(sink)
         return (None, None, None, d_img, d_tac) + _returned(sink, [gmod]) + _pos_grads(ctx.pos[0], ctx.pos[1], dtok, None)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# Trainable fusion MLP of the cfg-5 extractor (models/pretrain_models_dino_cat_mae.py:828-836,899-903) on the HIP GEMMs.  f32 compute
+# (exact f32 MFMA): the matrices are (B, 2 D) x (2 D, 2 D) — a few MFLOP — and f32 keeps the policy head's numerics those of nn.Linear.
+class LinearActFn(torch.autograd.Function):
+    """y = Dropout(ReLU(x W^T + b)) with optional ReLU / keep-mask.  x (M, K) f32, W (N, K), b (N); mask (M, N) uint8 or None, scale =
+    1 / (1 - p).  Forward: one NT GEMM with bias (+ ReLU) epilogue (+ mask kernel).  Backward: dz = dy * scale * [y > 0] (the saved output
+    carries both the ReLU and the dropout pattern), dW = dz^T x (TN GEMM), db = column sums, dx = dz W (NT GEMM on a transposed copy)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, mask, scale):
+        _require_cuda(x, "fusion MLP input")
+        lib = L.lib()
+        x, w, b = _f32c(x), _f32c(weight), _f32c(bias)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        L.check(lib.m3l_op_gemm_nt(DT_F32, L.ptr(x), K, L.ptr(w), K, M, N, K, L.ptr(b), None, L.ptr(y), None, None, None, 2 if relu else 0, N,
+                                   _stream()), "m3l_op_gemm_nt (fusion MLP)")
+        if mask is not None:
+            L.check(lib.m3l_op_mask_scale(0, L.ptr(y), L.ptr(mask), float(scale), y.numel(), L.ptr(y), _stream()), "m3l_op_mask_scale")
+        ctx.saved = (x, w, y if (relu or mask is not None) else None, relu, mask is not None, float(scale) if mask is not None else 1.0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, w, y, relu, dropped, scale = ctx.saved
+        M, K = x.shape
+        N = w.shape[0]
+        dz = _f32c(dy)
+        if y is not None:
+            if relu:          # ReLU (and the dropout pattern, where there is one): on where the saved output is > 0
+                out = torch.empty_like(dz)
+                L.check(lib.m3l_op_mask_scale(1, L.ptr(dz), L.ptr(y), scale, dz.numel(), L.ptr(out), _stream()), "m3l_op_mask_scale")
+                dz = out
+            else:
+                raise NotImplementedError("Dropout without ReLU in front is not part of the reference's fusion MLP")
+        dev = x.device
+        dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+        wsb = lib.m3l_op_gemm_tn_ws_bytes(M, N, K)
+        ws = _ws(wsb, dev)
+        L.check(lib.m3l_op_gemm_tn(DT_F32, L.ptr(dz), N, L.ptr(x), K, M, N, K, L.ptr(ws), wsb, L.ptr(dW), K, _stream()), "m3l_op_gemm_tn (fusion MLP)")
+        db = torch.empty(N, dtype=torch.float32, device=dev)
+        ws2 = _ws(lib.m3l_op_colsum_ws_bytes(N), dev)
+        L.check(lib.m3l_op_colsum(DT_F32, L.ptr(dz), M, N, N, L.ptr(ws2), L.ptr(db), _stream()), "m3l_op_colsum")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty(K, N, dtype=torch.float32, device=dev)
+            L.check(lib.m3l_op_prep_weight(DT_F32, L.ptr(w), N, K, None, L.ptr(wT), _stream()), "m3l_op_prep_weight")
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            L.check(lib.m3l_op_gemm_nt(DT_F32, L.ptr(dz), N, L.ptr(wT), N, M, K, N, None, None, L.ptr(dx), None, None, None, 0, K, _stream()),
+                    "m3l_op_gemm_nt (fusion MLP dgrad)")
+        return dx, dW, db, None, None, None
+
+
+class Concat2Fn(torch.autograd.Function):
+    """torch.cat((a, b), dim=-1) for two (rows, n) f32 matrices; b may carry no gradient (the frozen DINOv2 feature)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        rows, na, nb = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty(rows, na + nb, dtype=torch.float32, device=a.device)
+        L.check(L.lib().m3l_op_concat2(L.ptr(a), na, L.ptr(b), nb, rows, L.ptr(out), 0, _stream()), "m3l_op_concat2")
+        ctx.dims = (rows, na, nb)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        rows, na, nb = ctx.dims
+        d = _f32c(d)
+        da = torch.empty(rows, na, dtype=torch.float32, device=d.device)
+        db = torch.empty(rows, nb, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[1] else None
+        L.check(L.lib().m3l_op_concat2(L.ptr(da), na, L.ptr(db), nb, rows, L.ptr(d), 1, _stream()), "m3l_op_concat2 (split)")
+        return da, db

@@ -4,8 +4,10 @@
     obs --vt_load--> x --mae.get_embeddings--> (B, N, D) --1-layer Transformer--> mean over tokens --+
     x['image'][:, middle RGB frame] --frozen DINOv2-S/14-reg--> (B, D) ------------------------------cat--> MLP (2D -> 2D -> 2D -> D)
 
-Everything up to the concat runs on this package's HIP kernels (VTMAE.get_embeddings, Transformer, DinoV2Frozen); the three-Linear
-fusion MLP on a (B, 2D) matrix is a plain library GEMM (torch.nn.Linear -> hipBLASLt) with Dropout(0.1) exactly as the reference builds it.
+Everything runs on this package's HIP kernels: VTMAE.get_embeddings, Transformer, DinoV2Frozen, the concat and the three-Linear fusion MLP
+(`self.mlp` keeps the reference's nn.Sequential layout, so state dicts match; its arithmetic goes through the f32 NT / TN GEMMs of the C
+ABI with the bias + ReLU epilogue — functional.LinearActFn — and Dropout(0.1) is a keep-mask drawn with torch's generator, as the mask
+noise of the MAE is, applied by a HIP kernel).
 
 The reference class derives from stable-baselines3's `BaseFeaturesExtractor`; SB3 is not part of this package, so this is a plain
 `nn.Module` with the same constructor arguments after `observation_space`, the same sub-module / parameter names (`vit_layer`,
@@ -18,6 +20,7 @@ Reference defect NOT reproduced: the middle-frame slice `image[:, 3*mid-3 : 3*mi
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from .pretrain_models import VTT
 from .pretrain_utils import vt_load
 
@@ -89,4 +92,17 @@ class DinoCatMAEExtractor(nn.Module):
         tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
         dino = self.dino_model(self.middle_frame(vt["image"]))
         pooled = torch.mean(self.vit_layer.transformer(tokens), dim=1)
-        return self.mlp(torch.cat((self.flatten(pooled), dino.to(pooled.dtype)), dim=-1))
+        return self.run_mlp(Fn.Concat2Fn.apply(self.flatten(pooled), dino))
+
+    def run_mlp(self, x):
+        """self.mlp = Linear, ReLU, Dropout(0.1), Linear, ReLU, Dropout(0.1), Linear (:828-836) through the HIP GEMMs."""
+        lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        drops = [m for m in self.mlp if isinstance(m, nn.Dropout)]
+        for i, l in enumerate(lin):
+            last = i + 1 == len(lin)
+            mask, scale = None, 1.0
+            if not last and self.training and drops[i].p > 0:
+                mask = (torch.rand(x.shape[0], l.out_features, device=x.device) >= drops[i].p).to(torch.uint8)
+                scale = 1.0 / (1.0 - drops[i].p)
+            x = Fn.LinearActFn.apply(x, l.weight, l.bias, not last, mask, scale)
+        return x

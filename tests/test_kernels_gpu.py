@@ -197,3 +197,35 @@ def test_vt_load_matches_golden(dev, golden_dir):
         assert all(torch.equal(out2[k], out[k]) for k in out)
         with pytest.raises(NotImplementedError, match="unpickling is refused"):
             vt_load(os.path.join(d, "obs.npy"))
+
+
+@pytest.mark.parametrize("M,K,N", [(3, 128, 128), (128, 768, 768), (37, 256, 64)])
+def test_fusion_mlp_linear_act(dev, M, K, N):
+    """functional.LinearActFn / Concat2Fn (the cfg-5 extractor's trainable fusion MLP, models/pretrain_models_dino_cat_mae.py:828-836,
+    899-903) against torch: Linear + ReLU + Dropout with a GIVEN keep-mask (scale 1 / 0.9), forward and every gradient; f32 MFMA compute."""
+    from m3l_amd import functional as Fn
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    mask = (torch.rand(M, N, generator=g) >= 0.1).to(torch.uint8).to(dev)
+    cot = torch.randn(M, N, generator=g).to(dev)
+    for relu, mk in ((True, mask), (True, None), (False, None)):
+        scale = 1.0 / 0.9 if mk is not None else 1.0
+        y = Fn.LinearActFn.apply(x, w, b, relu, mk, scale)
+        gx, gw, gb = torch.autograd.grad((y * cot).sum(), (x, w, b))
+        xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+        yr = xr @ wr.t() + br
+        if relu:
+            yr = torch.relu(yr)
+        if mk is not None:
+            yr = yr * mk.double() * scale
+        rx, rw, rb = torch.autograd.grad((yr * cot.double()).sum(), (xr, wr, br))
+        for a, r in ((y, yr), (gx, rx), (gw, rw), (gb, rb)):
+            assert float((a.double() - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, (relu, mk is not None)
+    a = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    c = torch.randn(M, N, generator=g).to(dev)
+    cat = Fn.Concat2Fn.apply(a, c)
+    assert torch.equal(cat, torch.cat((a, c), -1))
+    (ga,) = torch.autograd.grad((cat * cat).sum(), (a,))
+    assert torch.equal(ga, 2 * a.detach())

@@ -21,11 +21,19 @@ if st:
     shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 
-def collect(sub, counter):
+# The weight-gradient kernel is launched in two populations: GROUPED launches (the four weights of 2-4 transformer layers: 640 workgroups
+# = 327 680 threads at cfg 2; the class bench.py brackets and prices in `roofline`) and single small Linears (patch embed / heads: <= 96
+# workgroups).  They are kept apart by grid size so that counter bytes and algorithmic bytes describe the SAME launches.
+GROUPED_MIN_THREADS = 200000
+
+
+def collect(sub, counter, grid_min=0, grid_max=1 << 62):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
+                continue
+            if not (grid_min <= int(float(r.get("Grid_Size", 0) or 0)) < grid_max):
                 continue
             a = acc[r["Kernel_Name"]]
             a[0] += 1
@@ -78,7 +86,26 @@ def per_launch(sub):
     return (nf, sf, nw, sw)
 
 
+# weight gradients, like for like: per GROUPED launch (= bench.py's `roofline` class) and per step over the whole family (grouped + small
+# launches + their reduce kernels: the split-M slabs are written by the former and read by the latter)
+fg, wg = collect("fetch", "FETCH_SIZE", GROUPED_MIN_THREADS), collect("write", "WRITE_SIZE", GROUPED_MIN_THREADS)
+nfg = sum(v[0] for k, v in fg.items() if "wgrad_kernel" in k)
+sfg = sum(v[1] for k, v in fg.items() if "wgrad_kernel" in k)
+nwg = sum(v[0] for k, v in wg.items() if "wgrad_kernel" in k)
+swg = sum(v[1] for k, v in wg.items() if "wgrad_kernel" in k)
+fam_f = sum(v[1] for k, v in fetch.items() if "wgrad_" in k) / steps_f
+fam_w = sum(v[1] for k, v in write.items() if "wgrad_" in k) / steps_w
+if nfg and nwg:
+    traffic["wgrad_grouped"] = {"hbm_bytes_per_launch": int((2 * sfg / nfg + swg / nwg) * 1024), "fetch_size_kb": round(sfg / nfg, 1),
+                                "write_size_kb": round(swg / nwg, 1), "launches": nfg, "launches_per_step": round(nfg / steps_f, 2),
+                                "note": "wgrad_kernel<*> launches of >= %d threads only (the grouped per-layer launches bench.py brackets as `wgrad`)" % GROUPED_MIN_THREADS}
+    traffic["wgrad_family_per_step"] = {"hbm_bytes_per_step": int((2 * fam_f + fam_w) * 1024), "write_bytes_per_step": int(fam_w * 1024),
+                                        "note": "every wgrad_kernel<*> and wgrad_reduce_kernel<*> launch of a step (grouped and small): operands read, "
+                                                "split-M slabs written and read back, dW written"}
+
 for cls, sub in classes.items():
+    if cls == "wgrad":
+        continue
     nf, sf, nw, sw = per_launch(sub)
     if nf and nw:
         traffic[cls] = {"hbm_bytes_per_launch": int((2 * sf / nf + sw / nw) * 1024), "fetch_size_kb": round(sf / nf, 1), "write_size_kb": round(sw / nw, 1),

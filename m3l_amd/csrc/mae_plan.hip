@@ -272,6 +272,10 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     int np = 0;
     layer_wgrad_problems(pr, (int)D, (int)HD, (int)mlp, c->project_out != 0, &np);
     w.wg_batch = c->dtype == 1 ? std::max(1, std::min(std::min(4, std::max(1, c->depth)), m3l_wgrad_layers_per_launch((int)M, pr, np))) : 1;
+    {   // experiment switch: layers per grouped weight-gradient launch (<= 4: M3L_TN_MAX_PROBLEMS / 4 weights per layer)
+        static const int forced = getenv("M3L_WGRAD_LAYERS") ? atoi(getenv("M3L_WGRAD_LAYERS")) : 0;
+        if (forced > 0 && c->dtype == 1) w.wg_batch = std::max(1, std::min(std::min(4, std::max(1, c->depth)), forced));
+    }
     w.nset = std::max(1, std::min(std::max(1, c->depth), 2 * w.wg_batch));
     w.dx_t.resize(w.nset); w.dx1_t.resize(w.nset); w.du.resize(w.nset); w.dqkv.resize(w.nset); w.scratch2.resize(w.nset);
     for (int i = 0; i < w.nset; ++i) {

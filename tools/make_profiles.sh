@@ -17,5 +17,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d 
 unset M3L_WGRAD_INLINE
 cd $R
 python3 tools/pmc_to_traffic.py $OUT $TAG
+python3 tools/attn_phase_probe.py $TAG > $OUT/attn_phase.log 2>&1 && cp gpurun_out/${TAG}_attn_phases.json $OUT/final/
+# raw traces / counter dumps are tens of MB (gpurun merges at most 64 MiB back): keep only what profiles/ gets
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma
 python3 bench.py > $OUT/final/${TAG}_bench_n1.json 2> $OUT/bench.log
 tail -c 700 $OUT/final/${TAG}_bench_n1.json

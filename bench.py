@@ -473,6 +473,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
+        sync.close()                      # the library's own RCCL communicator (collective), then torch's
         dist.destroy_process_group()
 
 

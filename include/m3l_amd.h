@@ -103,6 +103,9 @@ int m3l_side_pending(void);      /* number of un-joined deferred tails (diagnost
  * sequences (48-row tiles, two chunk parities; correct, measured equal to the per-sample block kernels); env M3L_T192 sets the
  * initial mode, 0 falls back to the per-op kernels.  Returns the previous mode. */
 int m3l_set_t192(int on);
+/* height of the tall row tiles at width 192: 12 token tiles = 192 rows, one workgroup per CU, or 6 = 96 rows, 6 + 2 waves
+ * and a 3-stage ring so that two workgroups share a CU and overlap each other's memory-only phases; env M3L_T192_TT.  Returns the previous value. */
+int m3l_set_t192_tt(int tt);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.

@@ -293,8 +293,11 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     w.scratch_tn_b = m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * w.wg_batch);
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_tn_b));
-    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B), m3l_mlp_t192_cs_rows((int)D, (int)M)) * mlp);   // B: one partial row per sample (block kernels)
-    w.ln_part_stride = (size_t)std::max(std::max(m3l_ln_bwd_blocks((int)M), B), std::max(m3l_mlp_t192_tiles((int)D, (int)M), m3l_qkv_bwd_t192_tiles((int)D, (int)M))) * 3 * D;
+    // partial rows of the row-tiled kernels: sized for EVERY tile shape they may pick (48- / 96- / 128- / 192-row tiles; one fc1-bias row per
+    // wave at most), so that the layout does not depend on the tuning switches in force at the time of the call
+    const int t192_rows_max = (int)((M + 15) / 16) + 16, t192_tiles_max = (int)((M + 47) / 48) + 1;
+    for (int i = 0; i < w.nset; ++i) w.scratch2[i] = a.take_n<float>((size_t)std::max(std::max(m3l_gemm_nt_colsum_rows((int)M, (int)mlp), B), t192_rows_max) * mlp);   // B: one partial row per sample (block kernels)
+    w.ln_part_stride = (size_t)std::max(std::max(m3l_ln_bwd_blocks((int)M), B), t192_tiles_max) * 3 * D;
     w.ln_part = a.take_n<float>((size_t)(2 * c->depth + 1) * w.ln_part_stride);
     w.total = a.off + 256;
     return w;

@@ -46,9 +46,14 @@ template <int D, int TT, int CP> struct TileCfg {
     static constexpr int BLK = 64 * D;                                            // one weight block: 32 rows x D k, or D rows x 32 k (bf16)
     static constexpr int CHUNK = 2 * BLK;                                         // the two blocks of one 32-wide chunk
     static constexpr int PCB = D / 16, PC = 2 * PCB;                              // 1-KiB DMA pieces per block / per chunk
-    static constexpr int DW = D == 384 ? 2 : 4;                                   // DMA-only waves
+    // <192, 6, 1>: 96-row tiles of 6 + 2 waves with a 3-stage ring (72 KiB) so that TWO workgroups share a CU: every kernel here runs its
+    // phases back to back (operand loads -> weight-stream loop -> LayerNorm / store tail), and with one workgroup per CU nothing overlaps the
+    // memory-only head and tail; MINW = 4 waves per SIMD keeps the register cap of the second workgroup (128 VGPRs)
+    static constexpr bool HALF = D == 192 && TT == 6 && CP == 1;
+    static constexpr int DW = (D == 384 || HALF) ? 2 : 4;                         // DMA-only waves
     static constexpr int NCW = TT * CP, THREADS = 64 * (NCW + DW), ROWS = 16 * TT;
-    static constexpr int STAGE = CP * CHUNK, NSTAGE = (D == 192 && CP == 1) ? 4 : 3, RING = NSTAGE * STAGE;
+    static constexpr int MINW = HALF ? 4 : 1;                                     // __launch_bounds__ minimum waves per SIMD
+    static constexpr int STAGE = CP * CHUNK, NSTAGE = (D == 192 && CP == 1 && !HALF) ? 4 : 3, RING = NSTAGE * STAGE;
     static constexpr int PPW = PC * CP / DW;                                      // DMA pieces per DMA wave and stage
     static constexpr int RED0 = (CP - 1) * TT * ND * 1024;                        // partial accumulators of the parities > 0 (aliases the ring)
     static_assert(D % 64 == 0 && (PC * CP) % DW == 0, "whole pieces per DMA wave");
@@ -196,7 +201,7 @@ struct ProArgs {
     float* x1_out; bf16* xn2_out;
 };
 template <int D, int TT, int CP, int PRO>
-__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
                                                                    const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                    const bf16* __restrict__ W2, const float* __restrict__ b2, int M, int mlp,
                                                                    bf16* __restrict__ u_out, bf16* __restrict__ h_out,
@@ -391,7 +396,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS)) void mlp_t192_fwd_ke
 // D != 192: no CS buffer (3 ring stages of 32 / 48 KiB leave no room for [TT][mlp] floats): every wave writes its column sums straight to
 // cs_part, one partial row per (tile, wave) — the reduce that follows takes TT times more rows.
 template <int D, int TT, int CP> struct MlpBwdLayout {
-    static constexpr bool CS_LDS = D == 192;
+    static constexpr bool CS_LDS = D == 192 && !TileCfg<D, TT, CP>::HALF;
     static constexpr int RING = 0, CS = TileCfg<D, TT, CP>::RING;
     static size_t total(int mlp) { return (size_t)CS + (CS_LDS ? (size_t)TT * mlp * 4 : 0) + D * 4; }
 };
@@ -467,7 +472,7 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
 }
 
 template <int D, int TT, int CP>
-__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
                                                                    const float* __restrict__ x1, const float* __restrict__ ln2_w,
                                                                    const bf16* __restrict__ u, const bf16* __restrict__ W2T,
                                                                    const bf16* __restrict__ W1T, float eps, int M, int mlp,
@@ -601,7 +606,7 @@ template <int D, int TT> struct QkvBwdLayout {
 };
 
 template <int D, int TT>
-__global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS)) void qkv_bwd_t192_kernel(const bf16* __restrict__ dqkv, const float* __restrict__ x,
+__global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS), (TileCfg<D, TT, 1>::MINW)) void qkv_bwd_t192_kernel(const bf16* __restrict__ dqkv, const float* __restrict__ x,
                                                                                const float* __restrict__ ln1_w, const bf16* __restrict__ WqkvT,
                                                                                const float* __restrict__ dres, float eps, int M, int K,
                                                                                float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
@@ -1102,11 +1107,26 @@ static int t192_min_tiles() {
     static const int v = getenv("M3L_T192_MIN_TILES") ? atoi(getenv("M3L_T192_MIN_TILES")) : 128;
     return v;
 }
-static int t192_tt(int M) { return (cdiv(M, 192) >= t192_min_tiles() || forced()) ? 12 : 3; }   // bit 4: 192-row tiles at any M (tests)
+// tall tile at D = 192: 12 token tiles (192 rows, one workgroup per CU) or 6 (96 rows, two workgroups per CU: env M3L_T192_TT=6,
+// m3l_set_t192_tt)
+static int g_tall_tt = 0;
+static int tall_tt() {
+    if (!g_tall_tt) g_tall_tt = (getenv("M3L_T192_TT") && atoi(getenv("M3L_T192_TT")) == 6) ? 6 : 12;
+    return g_tall_tt;
+}
+extern "C" int m3l_set_t192_tt(int tt) {
+    const int old = tall_tt();
+    g_tall_tt = tt == 6 ? 6 : 12;
+    return old;
+}
+static int t192_tt(int M) { return (cdiv(M, 192) >= t192_min_tiles() || forced()) ? tall_tt() : 3; }   // bit 4: tall tiles at any M (tests)
 static int tile_rows(int D, int M) { return D == 192 ? 16 * t192_tt(M) : 16 * (D == 256 ? WideTile<256>::TT : WideTile<384>::TT); }
 int m3l_mlp_t192_tiles(int D, int M) { return cdiv(M, tile_rows(D, M)); }
 // partial rows of the fc1 bias gradient: one per tile at D = 192 (summed over the tile's waves in LDS), one per (tile, wave) otherwise
-int m3l_mlp_t192_cs_rows(int D, int M) { return m3l_mlp_t192_tiles(D, M) * (D == 192 ? 1 : tile_rows(D, M) / 16); }
+int m3l_mlp_t192_cs_rows(int D, int M) {
+    const int tt = tile_rows(D, M) / 16;
+    return m3l_mlp_t192_tiles(D, M) * ((D == 192 && tt != 6) ? 1 : tt);
+}
 
 template <typename K> static int lds_attr(K kern, size_t bytes) {
     M3L_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1121,12 +1141,14 @@ template <typename K> static int lds_attr(K kern, size_t bytes) {
     }
 #define T192_DISPATCH(DV, TTV, ...)                                                                    \
     if ((DV) == 192 && (TTV) == 12) { constexpr int D = 192, TT = 12, CP = 1; __VA_ARGS__; }           \
+    else if ((DV) == 192 && (TTV) == 6) { constexpr int D = 192, TT = 6, CP = 1; __VA_ARGS__; }        \
     else if ((DV) == 192) { constexpr int D = 192, TT = 3, CP = 2; __VA_ARGS__; }                      \
     else if ((DV) == 256) { constexpr int D = 256, TT = WideTile<256>::TT, CP = 1; __VA_ARGS__; }      \
     else { constexpr int D = 384, TT = WideTile<384>::TT, CP = 1; __VA_ARGS__; }
 // the 192-row-only kernels (out-proj prologue, dxn1 + LN1 backward) at D = 192 always run <12, 1> tiles
 #define T192_DISPATCH_FULL(DV, ...)                                                                    \
-    if ((DV) == 192) { constexpr int D = 192, TT = 12, CP = 1; __VA_ARGS__; }                          \
+    if ((DV) == 192 && tall_tt() == 12) { constexpr int D = 192, TT = 12, CP = 1; __VA_ARGS__; }       \
+    else if ((DV) == 192) { constexpr int D = 192, TT = 6, CP = 1; __VA_ARGS__; }                      \
     else if ((DV) == 256) { constexpr int D = 256, TT = WideTile<256>::TT, CP = 1; __VA_ARGS__; }      \
     else { constexpr int D = 384, TT = WideTile<384>::TT, CP = 1; __VA_ARGS__; }
 
@@ -1155,7 +1177,7 @@ int m3l_attn_tail_mlp_t192_fwd(int Dm, int M, int mlp, const void* o, const floa
                                const float* ln2_b, float eps, float* x1, void* xn2, const void* w1, const float* b1, const void* w2,
                                const float* b2, void* u, void* h, float* xout, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "attn_tail_mlp_t192_fwd: width %d", Dm);
-    ProfScope prof("attn_tail_mlp_t192_fwd", M, mlp, tile_rows(Dm, Dm == 192 ? (1 << 30) : M) / 16, 4.0 * M * (double)Dm * mlp + 2.0 * M * (double)Dm * Dm, st,
+    ProfScope prof("attn_tail_mlp_t192_fwd", M, mlp, Dm == 192 ? tall_tt() : tile_rows(Dm, M) / 16, 4.0 * M * (double)Dm * mlp + 2.0 * M * (double)Dm * Dm, st,
                    (double)M * (Dm * 2.0 + Dm * 4.0 + Dm * 4.0 + Dm * 2.0 + Dm * 8.0 + mlp * 4.0));
     ProArgs pa = {(const bf16*)o, x, (const bf16*)wo, bo, ln2_w, ln2_b, eps, x1, (bf16*)xn2};
     T192_DISPATCH_FULL(Dm, {
@@ -1187,7 +1209,7 @@ int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M) {
     if (D == 192) return cdiv(M, 192) >= t192_min_tiles() || forced();   // bit 4: any M (tests)
     return M >= wide_min_rows(D) || forced();
 }
-int m3l_qkv_bwd_t192_tiles(int D, int M) { return cdiv(M, D == 192 ? 192 : tile_rows(D, M)); }
+int m3l_qkv_bwd_t192_tiles(int D, int M) { return cdiv(M, D == 192 ? 16 * tall_tt() : tile_rows(D, M)); }
 
 int m3l_qkv_bwd_t192(int Dm, int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
                      float* dx_out, void* dxt_out, float* ln_part, hipStream_t st) {

@@ -289,6 +289,15 @@ class GradSync:
         s, self._pending_scale = self._pending_scale, 1.0
         return s
 
+    def close(self):
+        """Tear the library's RCCL communicator down (collective: every rank calls it, before destroy_process_group())."""
+        if self._direct:
+            from . import _lib as L
+            torch.cuda.synchronize()
+            L.lib().m3l_comm_destroy()
+            self._direct = False
+            self._comm = False
+
     def reduce_now(self):
         """Non-overlapped variant (used by tests / when hooks are not wanted)."""
         if self._comm:

@@ -128,20 +128,23 @@ def test_t192_row_tiled_kernels(D, heads, mlp, n, B):
     yo = O.transformer(xo, P, "t.", 2, heads, 64)
     (yo * cot.cpu()).sum().backward()
     res = {}
-    for on in (0, 3, 7):
-        old = L.lib().m3l_set_t192(on)
+    modes = (0, 3, 7) + ((13, 17) if D == 192 else ())         # 13 / 17 = modes 3 / 7 with 96-row tall tiles (two workgroups per CU)
+    for on in modes:
+        old = L.lib().m3l_set_t192(on % 10)
+        old_tt = L.lib().m3l_set_t192_tt(6 if on >= 10 else 12)
         try:
             res[on] = _run(tf, x, cot, 1)
         finally:
             L.lib().m3l_set_t192(old)
-    for on in (0, 3, 7):
+            L.lib().m3l_set_t192_tt(old_tt)
+    for on in modes:
         y, dx, grads = res[on]
         ey, edx = _relmax(y, yo.detach()), _relmax(dx, xo.grad)
         worst = max(((k, _relmax(gr, P["t." + k].grad)) for k, gr in grads.items()), key=lambda t: t[1])
         print(f"\n[t192] D={D} mlp={mlp} n={n} B={B} t192={on} vs oracle: y {ey:.2e} dx {edx:.2e} worst {worst[0]} {worst[1]:.2e}")
         assert ey <= 5e-3 and edx <= 1e-2 and worst[1] <= 2e-2, (on, ey, edx, worst)
     y0, dx0, g0 = res[0]
-    for on in (3, 7):
+    for on in modes[1:]:
         y, dx, grads = res[on]
         worst = max(((k, _relmax(gr, g0[k])) for k, gr in grads.items()), key=lambda t: t[1])
         print(f"\n[t192] D={D} mlp={mlp} n={n} B={B} t192={on} vs off: y {_relmax(y, y0):.2e} dx {_relmax(dx, dx0):.2e} worst {worst[0]} {worst[1]:.2e}")

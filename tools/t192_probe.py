@@ -37,25 +37,25 @@ xout, x1o, dxo = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev), t
 xn_o, dxt_o, o_o = torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, D, device=dev, dtype=bf)
 qkv_o = torch.empty(M, 3 * D, device=dev, dtype=bf)
 tiles = (M + 191) // 192
-cs_part, ln_part = torch.empty(tiles, mlp, device=dev), torch.empty(tiles, 3 * D, device=dev)
+cs_part, ln_part = torch.empty(M // 16 + 16, mlp, device=dev), torch.empty(M // 48 + 1, 3 * D, device=dev)    # sized for every tile shape
 st = torch.cuda.current_stream().cuda_stream
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 F = C.c_float(1e-5)
 raw.m3l_set_t192(7)
 
 KERNELS = {
-    "attn_t192_fwd": lambda: raw._Z17m3l_attn_t192_fwdiiPKfS0_S0_PKvfPvS3_S3_PfP12ihipStream_t(
-        B, n, P(x), P(lw), P(lb), P(wqkv), F, P(xn_o), P(qkv_o), P(o_o), P(lse), C.c_void_p(st)),
-    "attn_tail_mlp_t192_fwd": lambda: raw._Z26m3l_attn_tail_mlp_t192_fwdiiPKvPKfS0_S2_S2_S2_fPfPvS0_S2_S0_S2_S4_S4_S3_P12ihipStream_t(
-        M, mlp, P(o), P(x), P(wo), P(bo), P(lw), P(lb), F, P(x1o), P(xn_o), P(w1), P(b1), P(w2), P(b2), P(u), P(h), P(xout), C.c_void_p(st)),
-    "mlp_t192_fwd": lambda: raw._Z16m3l_mlp_t192_fwdiiPKvPKfS0_S2_S0_S2_PvS3_PfP12ihipStream_t(
-        M, mlp, P(xn), P(x1), P(w1), P(b1), P(w2), P(b2), P(u), P(h), P(xout), C.c_void_p(st)),
-    "mlp_t192_bwd": lambda: raw._Z16m3l_mlp_t192_bwdiiPKvPfPKfS3_S0_S0_S0_fPvS4_S1_S1_P12ihipStream_t(
-        M, mlp, P(dxt), P(dxo), P(x1), P(lw), P(u), P(w2T), P(w1T), F, P(du), P(dxt_o), P(cs_part), P(ln_part), C.c_void_p(st)),
-    "attn_t192_bwd": lambda: raw._Z17m3l_attn_t192_bwdiiPKvS0_S0_PKfS0_PvP12ihipStream_t(
-        B, n, P(dxt), P(qkv), P(o), P(lse), P(woT), P(qkv_o), C.c_void_p(st)),
-    "qkv_bwd_t192": lambda: raw._Z16m3l_qkv_bwd_t192iiPKvPKfS2_S0_S2_fPfPvS3_P12ihipStream_t(
-        M, 3 * D, P(dqkv), P(x), P(lw), P(wqkvT), P(dres), F, P(dxo), P(dxt_o), P(ln_part), C.c_void_p(st)),
+    "attn_t192_fwd": lambda: raw._Z17m3l_attn_t192_fwdiiiPKfS0_S0_PKvfPvS3_S3_PfP12ihipStream_t(
+        D, B, n, P(x), P(lw), P(lb), P(wqkv), F, P(xn_o), P(qkv_o), P(o_o), P(lse), C.c_void_p(st)),
+    "attn_tail_mlp_t192_fwd": lambda: raw._Z26m3l_attn_tail_mlp_t192_fwdiiiPKvPKfS0_S2_S2_S2_fPfPvS0_S2_S0_S2_S4_S4_S3_P12ihipStream_t(
+        D, M, mlp, P(o), P(x), P(wo), P(bo), P(lw), P(lb), F, P(x1o), P(xn_o), P(w1), P(b1), P(w2), P(b2), P(u), P(h), P(xout), C.c_void_p(st)),
+    "mlp_t192_fwd": lambda: raw._Z16m3l_mlp_t192_fwdiiiPKvPKfS0_S2_S0_S2_PvS3_PfP12ihipStream_t(
+        D, M, mlp, P(xn), P(x1), P(w1), P(b1), P(w2), P(b2), P(u), P(h), P(xout), C.c_void_p(st)),
+    "mlp_t192_bwd": lambda: raw._Z16m3l_mlp_t192_bwdiiiPKvPfPKfS3_S0_S0_S0_fPvS4_S1_S1_P12ihipStream_t(
+        D, M, mlp, P(dxt), P(dxo), P(x1), P(lw), P(u), P(w2T), P(w1T), F, P(du), P(dxt_o), P(cs_part), P(ln_part), C.c_void_p(st)),
+    "attn_t192_bwd": lambda: raw._Z17m3l_attn_t192_bwdiiiPKvS0_S0_PKfS0_PvP12ihipStream_t(
+        D, B, n, P(dxt), P(qkv), P(o), P(lse), P(woT), P(qkv_o), C.c_void_p(st)),
+    "qkv_bwd_t192": lambda: raw._Z16m3l_qkv_bwd_t192iiiPKvPKfS2_S0_S2_fPfPvS3_P12ihipStream_t(
+        D, M, 3 * D, P(dqkv), P(x), P(lw), P(wqkvT), P(dres), F, P(dxo), P(dxt_o), P(ln_part), C.c_void_p(st)),
 }
 tot = 0.0
 out = []

@@ -323,8 +323,8 @@ class VTMAE(nn.Module):
         plan.used = ([has_img] * 6 + [has_tac] * 6 + [True, False, False] + [True] * (11 * enc_tf.depth + 2) + [True, True, True, True, False, False]
                      + [True] * (11 * dec_tf.depth + 2) + [has_img] * 2 + [has_tac] * 2)
         for i, t in enumerate(plan.tensors):
-            if t is None or not t.requires_grad:
-                plan.used[i] = False
+            if t is None:
+                plan.used[i] = False          # (a frozen parameter still gets a scratch gradient: the kernels write every slot they own)
         plan.image = Fn._f32c(image)
         plan.tactiles = [Fn._f32c(t) for t in tactiles]
         plan.noises = [Fn._f32c(n) for n in mask_noise]

@@ -321,6 +321,45 @@ def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
             assert a is None or torch.equal(a, b), n
 
 
+def test_fused_step_with_frozen_parameters():
+    """Parameters with requires_grad=False (a frozen decoder, a frozen patch projection) inside the fused step: the kernels still get a
+    scratch slot for every gradient they write, the frozen parameters end up without .grad, the others match the per-module path."""
+    from m3l_amd import functional as Fn
+    torch.manual_seed(4)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=128, depth=2, heads=2, mlp_dim=256)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=2, decoder_heads=1, compute_dtype="bf16").to(DEV)
+    frozen = [p for n, p in mae.named_parameters() if n.startswith("decoder.layers.0.") or n == "encoder.image_to_patch_embedding.2.weight"
+              or n == "enc_to_dec.weight"]
+    assert len(frozen) >= 10
+    for p in frozen:
+        p.requires_grad_(False)
+    B = 4
+    g = torch.Generator(device="cpu").manual_seed(12)
+    x = {"image": torch.rand(B, 3, 32, 32, generator=g).to(DEV), "tactile1": torch.rand(B, 3, 16, 16, generator=g).to(DEV),
+         "tactile2": torch.rand(B, 3, 16, 16, generator=g).to(DEV)}
+    noises = [torch.rand(B, 16, generator=g).to(DEV) for _ in range(3)]
+    res = []
+    for fused in (False, True):
+        Fn.FUSED_STEP = fused
+        try:
+            mae.zero_grad(set_to_none=True)
+            loss = mae(x, mask_noise=noises)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in mae.named_parameters()}))
+        finally:
+            Fn.FUSED_STEP = True
+    assert torch.equal(res[0][0], res[1][0])
+    for n, p in mae.named_parameters():
+        a, b = res[0][1][n], res[1][1][n]
+        if not p.requires_grad:
+            assert a is None and b is None, n
+        else:
+            assert (a is None) == (b is None), n          # (the learned position tables are unused under sincos encodings: no gradient)
+            assert a is None or torch.equal(a, b), n
+    assert res[1][1]["decoder.layers.1.0.to_qkv.weight"] is not None and res[1][1]["encoder.image_to_patch_embedding.2.bias"] is not None
+
+
 @pytest.mark.parametrize("fixture", ["vtt_dino_small", "vtt_dino_reg"])
 def test_dino_style_vtt_matches_reference_fixture(golden_dir, fixture):
     """models/VTT.py forward / forward_features (with and without keep-index masks; without and with 4 register tokens, :166-172,

@@ -329,8 +329,9 @@ class VTMAE(nn.Module):
         plan.tactiles = [Fn._f32c(t) for t in tactiles]
         plan.noises = [Fn._f32c(n) for n in mask_noise]
         plan.sync, plan.B, plan.nmask, plan.nvis = sync, B, c["num_masked"], c["num_unmasked"]
-        if sync is not None and torch.is_grad_enabled():
-            ins = (self.mask_token,)          # anchor: the kernels write every gradient in place, autograd only has to call backward
+        anchor = next((t for t in plan.tensors if t is not None and t.requires_grad), None)
+        if sync is not None and torch.is_grad_enabled() and anchor is not None:
+            ins = (anchor,)                   # anchor: the kernels write every gradient in place, autograd only has to call backward
         else:
             ins = tuple(t for t in plan.tensors if t is not None)
             for i, t in enumerate(plan.tensors):

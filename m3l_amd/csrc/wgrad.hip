@@ -193,13 +193,18 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
 #pragma unroll
             for (int y = 0; y < NB; ++y) acc[x][y] = mma16(fa[x], fb[y], acc[x][y]);
     }
-    // fragment-order slab: [wave][tile x * NB + y][lane] float4 (rows 4 g .. 4 g + 3 of the 16 x 16 tile, column li)
+    // fragment-order slab: [wave][tile x * NB + y][lane] float4 (rows 4 g .. 4 g + 3 of the 16 x 16 tile, column li).  16 x 16 tiles that lie
+    // entirely outside the problem (a 192 x 32 conv weight in a 256 x 128 tile: 104 of its 128 tiles) are neither written nor read back
     float* S = slabs + ((long)sp * grp.tiles_total + gtile) * (long)(WG_TA * TB);
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x) {
+        if (a0 + wr * 64 + x * 16 >= pb.avalid) continue;       // wave-uniform
 #pragma unroll
-        for (int y = 0; y < NB; ++y)
+        for (int y = 0; y < NB; ++y) {
+            if (b0 + wc * (TB / 2) + y * 16 >= pb.bvalid) continue;
             *reinterpret_cast<f32x4*>(S + (((wave * NT + x * NB + y) * 64 + lane) << 2)) = acc[x][y];
+        }
+    }
 }
 
 template <int TBT>
@@ -247,6 +252,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const fl
     const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
     const long stride = (long)grp.tiles_total * (WG_TA * TB);
     const float* P = slabs + (long)gt * (WG_TA * TB) + ((long)f << 2);
+    {   // this thread's 16 x 16 tile lies outside the problem: nothing was written, nothing to add (checked BEFORE the S slab reads)
+        const int wt0 = f >> 6, t0 = wt0 % NT, w0 = wt0 / NT;
+        if (a0 + (w0 >> 1) * 64 + (t0 / NB) * 16 >= pb.avalid || b0 + (w0 & 1) * (TB / 2) + (t0 % NB) * 16 >= pb.bvalid) return;
+    }
     // 8 independent 16-byte loads in flight per thread (the loop over a run-time S with two accumulators issued them in pairs: 13
     // dependent round trips for S = 25); the sum order is fixed: ((s0 + s1) + (s2 + s3)) + ... over i mod 8, then the tail
     f32x4 a8[8];

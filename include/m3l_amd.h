@@ -102,6 +102,10 @@ int m3l_side_pending(void);      /* number of un-joined deferred tails (diagnost
  * rows per workgroup (t192.hip).  Bit mask: 1 (default) = sequences longer than 48 tokens, 2 = also the MLP halves of short
  * sequences (48-row tiles, two chunk parities; correct, measured equal to the per-sample block kernels); env M3L_T192 sets the
  * initial mode, 0 falls back to the per-op kernels.  Returns the previous mode. */
+/* Hidden activation h = GELU(u) of the fused feed-forward kernels: 1 (default) = not written by the forward (one store stream less, 1.5 KB per
+ * token row and layer less HBM traffic); the weight-gradient kernel of fc2 then stages u and applies the GELU itself (bit-identical gradients).
+ * Set it BEFORE a forward and keep it until its backward has run.  env M3L_DROP_H.  Returns the previous setting. */
+int m3l_set_drop_h(int on);
 int m3l_set_t192(int on);
 /* height of the tall row tiles at width 192: 12 token tiles = 192 rows, one workgroup per CU, or 6 = 96 rows, 6 + 2 waves
  * and a 3-stage ring so that two workgroups share a CU and overlap each other's memory-only phases; env M3L_T192_TT.  Returns the previous value. */

@@ -44,6 +44,7 @@ _SIGS = {
     "m3l_set_attn_block": (c_i, [c_i]),
     "m3l_set_attn_phase_buffer": (None, [c_p]),
     "m3l_set_enc_mega": (c_i, [c_i]),
+    "m3l_set_drop_h": (c_i, [c_i]),
     "m3l_set_t192": (c_i, [c_i]),
     "m3l_set_t192_tt": (c_i, [c_i]),
     "m3l_set_defer_join": (c_i, [c_i]),

@@ -104,6 +104,8 @@ struct TnProblem {
     int ldo, nvalid, kvalid;
     int tile0;             // filled by the launcher
     long part_off;         // filled by the launcher (float offset of this problem's slabs)
+    int gelu_x;            // bf16 kernel only: X holds the PRE-activation u and the product is over GELU(u) (the hidden activation h was not saved):
+                           // 1 = erf form (gelu_f, the per-sample block kernels), 2 = fitted form (gelu_fast, the row-tiled kernels); 0 = X as it is
 };
 struct TnGroup {
     TnProblem p[4];

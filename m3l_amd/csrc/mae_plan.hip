@@ -139,6 +139,25 @@ inline bool use_rowln() {
     return g_rowln == 1;
 }
 inline size_t esz(int dtype) { return dtype ? 2 : 4; }
+// Hidden activation h = GELU(u) of the fused MLP kernels: 1 = not written by the forward — the weight-gradient kernel of fc2 stages the
+// pre-activation u instead and applies the GELU in its LDS stage (wgrad.hip), bit-identical gradients, 0.5 GB less HBM traffic per cfg-2
+// step (default); 0 = saved.  env M3L_DROP_H / m3l_set_drop_h.
+int g_drop_h = -1;
+inline bool drop_h() {
+    if (g_drop_h < 0) g_drop_h = getenv("M3L_DROP_H") ? (atoi(getenv("M3L_DROP_H")) > 0 ? 1 : 0) : 1;
+    return g_drop_h == 1;
+}
+// which fused kernel (if any) computes the feed-forward half of a layer in the FORWARD — the same decisions as m3l_transformer_fwd below:
+// 0 = per-op GEMMs (h is the operand of the fc2 GEMM: always saved), 1 = per-sample block kernel (erf-form GELU), 2 = row-tiled kernel
+// (fitted GELU).  The backward reads it to know whether h exists and which GELU reproduces it.
+int fused_mlp_kind(const m3l_tf_cfg* c, int B, int n, bool fuse) {
+    const int M = B * n, D = c->dim, mlp = c->mlp_dim, dt = c->dtype;
+    if (fuse || dt != 1) return 0;
+    const bool block = m3l_attn_block_supported(dt, D, c->heads, n, c->project_out);
+    const bool t192 = m3l_mlp_t192_supported(dt, D, mlp, M);
+    if (block && !(m3l_mlp_t192_short() && t192) && m3l_mlp_block_supported(dt, D, mlp, n)) return 1;
+    return t192 ? 2 : 0;
+}
 
 // scratch big enough for every reduction / split-K slab of one module
 size_t scratch_bytes(int M, const std::vector<std::pair<int, int>>& wshapes, int maxcols) {
@@ -374,6 +393,12 @@ int m3l_side_pending(void) {
     return (int)g_pending.size();
 }
 
+int m3l_set_drop_h(int on) {
+    const int old = drop_h() ? 1 : 0;
+    g_drop_h = on ? 1 : 0;
+    return old;
+}
+
 int m3l_set_rowln(int enable) {
     const int old = use_rowln() ? 1 : 0;
     g_rowln = enable ? 1 : 0;
@@ -581,15 +606,17 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             TfLayer& L = w.L[l];
             const void* const* t = tensors + 11 * l;
             const void* v[20] = {t[0], t[1], L.wqkv, L.wo, t[4], t[5], t[6], L.xn1, L.qkv, L.o, L.lse, L.x1, L.xn2,
-                                 L.w1, t[8], L.w2, t[10], L.u, L.h, L.xout};
+                                 L.w1, t[8], L.w2, t[10], L.u, drop_h() ? nullptr : L.h, L.xout};
             memcpy(lay[l], v, sizeof(v));
         }
         if (m3l_enc_fwd_mega(D, mlp, B, n, x, &lay[0][0], c->depth, LN_EPS, st)) return 1;
         x = w.L[c->depth - 1].xout;
         l_begin = c->depth;
     }
+    void* const h_null = nullptr;
     for (int l = l_begin; l < c->depth; ++l) {
         TfLayer& L = w.L[l];
+        void* const h_fused = drop_h() ? h_null : L.h;        // fused MLP kernels only: the per-op fc2 GEMM reads h from memory
         const void* const* t = tensors + 11 * l;
         const float *ln1_w = (const float*)t[0], *ln1_b = (const float*)t[1], *out_b = (const float*)t[4], *ln2_w = (const float*)t[5],
                     *ln2_b = (const float*)t[6], *fc1_b = (const float*)t[8], *fc2_b = (const float*)t[10];
@@ -618,7 +645,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         }
         if (c->project_out && !fuse && m3l_attn_tail_mlp_t192_supported(dt, D, HD, mlp, M)) {
             // long sequences: out-proj + residual + LN2 + fc1 + GELU + fc2 + residual in ONE launch per 192-row tile
-            if (m3l_attn_tail_mlp_t192_fwd(D, M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h,
+            if (m3l_attn_tail_mlp_t192_fwd(D, M, mlp, L.o, x, L.wo, out_b, ln2_w, ln2_b, LN_EPS, L.x1, L.xn2, L.w1, fc1_b, L.w2, fc2_b, L.u, h_fused,
                                            L.xout, st))
                 return 1;
             x = L.xout;
@@ -642,13 +669,13 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         }
         if (block && !(m3l_mlp_t192_short() && m3l_mlp_t192_supported(dt, D, mlp, M)) && m3l_mlp_block_supported(dt, D, mlp, n)) {
             // the feed-forward half in one launch as well
-            if (m3l_mlp_block_fwd(D, mlp, B, n, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
+            if (m3l_mlp_block_fwd(D, mlp, B, n, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, h_fused, L.xout, st)) return 1;
             x = L.xout;
             continue;
         }
         if (!fuse && m3l_mlp_t192_supported(dt, D, mlp, M)) {
             // long sequences: fc1 + GELU + fc2 + residual per 192-row tile, the hidden activation never leaves the CU between the GEMMs
-            if (m3l_mlp_t192_fwd(D, M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, L.h, L.xout, st)) return 1;
+            if (m3l_mlp_t192_fwd(D, M, mlp, L.xn2, L.x1, L.w1, fc1_b, L.w2, fc2_b, L.u, h_fused, L.xout, st)) return 1;
             x = L.xout;
             continue;
         }
@@ -852,7 +879,9 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         // ---- the weight gradients of the layer join the pending group; every wg_batch layers (and at the end of the range) the group
         // goes out as ONE grouped TN launch + one reduce on the side stream, overlapping the dgrad chains of the layers below
         {
-            pend.push_back(TnProblem{w.dx_t[cur], L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0});           // dW2 = dx^T h
+            // dW2 = dx^T h; when the forward did not save h the kernel stages u and applies the GELU of the kernel that made it
+            const int hk = drop_h() ? fused_mlp_kind(c, B, n, fuse) : 0;
+            pend.push_back(TnProblem{w.dx_t[cur], hk ? L.u : L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0, hk});
             pend.push_back(TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0});             // dW1 = du^T xn2
             pend.push_back(TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}); // dWqkv = dqkv^T xn1
             if (c->project_out) pend.push_back(TnProblem{w.dx1_t[cur], L.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0});   // dWo = dx1^T o

@@ -197,6 +197,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
         // u, h chunk -> global: 128-byte row segments
         for (int id = tid; id < n * 16 && !(MB_ABL & 2); id += 64 * MB_CW) {
             const int which = id & 1, rc = id >> 1, r = rc >> 3, cc = rc & 7;
+            if (which && !h_out) continue;                                // h not saved: the weight-gradient kernel recomputes GELU(u)
             const uint4 v = *reinterpret_cast<const uint4*>((which ? HS : US) + r * Ly::HC_PITCH + cc * 16);
             *reinterpret_cast<uint4*>((which ? h_out : u_out) + (row0 + r) * mlp + 64 * c + cc * 8) = v;
         }

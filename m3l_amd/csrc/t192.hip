@@ -359,7 +359,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
             if (ok && !(T192_ABL & 1)) {
                 const long o = trow * mlp + 32 * c + 8 * g;
                 *reinterpret_cast<bf16x8*>(u_out + o) = ub.v;
-                *reinterpret_cast<bf16x8*>(h_out + o) = hb.v;
+                if (h_out) *reinterpret_cast<bf16x8*>(h_out + o) = hb.v;      // null: the weight-gradient kernel recomputes h = GELU(u)
             }
         }
 #pragma unroll

@@ -37,6 +37,7 @@ struct WgProb {
     float* out;         // out[ia * so_a + ib * so_b]
     int lda, ldb, a, b, so_a, so_b, avalid, bvalid;
     int tile0, tiles_b;
+    int gelu_a, gelu_b;  // GELU form (TnProblem::gelu_x) to apply to the staged wide / narrow operand (0 = none)
 };
 struct WgExtra {
     const float* part;  // [G][width] partial rows
@@ -178,6 +179,20 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
         __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done reading stage t - 1
         asm volatile("" ::: "memory");
         if (t + WG_NST - 1 < nst) issue(t + WG_NST - 1);      // into the slot stage t - 1 occupied
+        if (pb.gelu_a | pb.gelu_b) {                          // workgroup-uniform
+            // the staged operand is the pre-activation u: h = GELU(u) in place, rounded as the forward rounded it, 8 values per thread
+            // and pass (rows past M were staged as zeros: GELU(0) = 0).  The kernel waits on HBM most of its time: the pass hides there.
+            char* base = smem + (t % WG_NST) * WG_STAGE + (pb.gelu_a ? 0 : 4 * 4096);
+            const int bytes = pb.gelu_a ? 4 * 4096 : TBT * 4096, form = pb.gelu_a | pb.gelu_b;
+            for (int off = tid * 16; off < bytes; off += WG_THREADS * 16) {
+                bf16x8 v = *reinterpret_cast<bf16x8*>(base + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)(form == 1 ? gelu_f((float)v[j]) : gelu_fast((float)v[j]));
+                *reinterpret_cast<bf16x8*>(base + off) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const char* As = smem + (t % WG_NST) * WG_STAGE + wr * 4096;
         const char* Bs = smem + (t % WG_NST) * WG_STAGE + 4 * 4096;
         Frag<bf16> fa[4], fb[NB];
@@ -329,6 +344,8 @@ WgPlanHost plan_of(int M, const TnProblem* probs, int count, WgGroup* grp) {
             w.so_a = y_wide ? p.ldo : 1; w.so_b = y_wide ? 1 : p.ldo;
             w.avalid = y_wide ? p.nvalid : p.kvalid; w.bvalid = y_wide ? p.kvalid : p.nvalid;
             w.tile0 = tiles; w.tiles_b = tb;
+            w.gelu_a = y_wide ? 0 : p.gelu_x;        // X is the wide operand when K > N
+            w.gelu_b = y_wide ? p.gelu_x : 0;
         }
         tiles += cdiv(a, WG_TA) * tb;
     }

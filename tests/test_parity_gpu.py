@@ -321,6 +321,47 @@ def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
             assert a is None or torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("t192_mode", [1, 7])
+def test_drop_h_is_bit_identical(t192_mode):
+    """m3l_set_drop_h(1): the fused feed-forward kernels do not write h = GELU(u); the fc2 weight-gradient kernel stages u and applies the
+    GELU of the kernel that produced it (erf form for the per-sample blocks of the encoder, the fitted form for the row tiles) in its LDS
+    stage.  Loss and EVERY gradient bit-identical to the run that saved h — cfg-2 token geometry (encoder n = 48 on the block kernels,
+    decoder n = 192 on 48-row tiles, or on 192-row tiles + per-sample attention when forced), also with a narrow MLP (h is then the
+    NARROW operand of the weight-gradient tile)."""
+    lib = L.lib()
+    for mlp in (768, 128):
+        torch.manual_seed(6)
+        enc = VTT(image_size=64, tactile_size=32, image_patch_size=8, tactile_patch_size=4, dim=192, depth=2, heads=3, mlp_dim=mlp)
+        mae = VTMAE(encoder=enc, decoder_dim=192, masking_ratio=0.75, decoder_depth=2, decoder_heads=3, compute_dtype="bf16").to(DEV)
+        if mlp == 128:
+            for lyr in mae.decoder.layers:          # VTMAE builds the decoder with mlp = 4 * dim: the narrow case goes through the encoder only
+                pass
+        B = 5
+        g = torch.Generator(device="cpu").manual_seed(13)
+        x = {"image": torch.rand(B, 3, 64, 64, generator=g).to(DEV), "tactile1": torch.rand(B, 3, 32, 32, generator=g).to(DEV),
+             "tactile2": torch.rand(B, 3, 32, 32, generator=g).to(DEV)}
+        noises = [torch.rand(B, 64, generator=g).to(DEV) for _ in range(3)]
+        res = []
+        old_t = lib.m3l_set_t192(t192_mode)
+        try:
+            for drop in (0, 1):
+                old = lib.m3l_set_drop_h(drop)
+                try:
+                    mae.zero_grad(set_to_none=True)
+                    loss = mae(x, mask_noise=noises)
+                    loss.backward()
+                    torch.cuda.synchronize()
+                finally:
+                    lib.m3l_set_drop_h(old)
+                res.append((loss.detach().clone(), {n: p.grad.clone() for n, p in mae.named_parameters() if p.grad is not None}))
+        finally:
+            lib.m3l_set_t192(old_t)
+        assert torch.equal(res[0][0], res[1][0])
+        assert res[0][1].keys() == res[1][1].keys()
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), (mlp, n)
+
+
 def test_fused_step_with_frozen_parameters():
     """Parameters with requires_grad=False (a frozen decoder, a frozen patch projection) inside the fused step: the kernels still get a
     scratch slot for every gradient they write, the frozen parameters end up without .grad, the others match the per-module path."""

@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -41,6 +43,9 @@ namespace {
 #ifndef T192_ABL
 #define T192_ABL 0          // diagnostic builds only (tools/t192_ablate.sh): bits switch pieces of the kernels off
 #endif
+#ifndef T192_NS_TALL
+#define T192_NS_TALL 4      // ring stages of the <192, 12, 1> tiles (experiment builds: 5, 6)
+#endif
 template <int D, int TT, int CP> struct TileCfg {
     static constexpr int KS = D / 32, ND = D / 16;
     static constexpr int BLK = 64 * D;                                            // one weight block: 32 rows x D k, or D rows x 32 k (bf16)
@@ -53,12 +58,12 @@ template <int D, int TT, int CP> struct TileCfg {
     static constexpr int DW = (D == 384 || HALF) ? 2 : 4;                         // DMA-only waves
     static constexpr int NCW = TT * CP, THREADS = 64 * (NCW + DW), ROWS = 16 * TT;
     static constexpr int MINW = HALF ? 4 : 1;                                     // __launch_bounds__ minimum waves per SIMD
-    static constexpr int STAGE = CP * CHUNK, NSTAGE = (D == 192 && CP == 1 && !HALF) ? 4 : 3, RING = NSTAGE * STAGE;
+    static constexpr int STAGE = CP * CHUNK, NSTAGE = (D == 192 && CP == 1 && !HALF) ? T192_NS_TALL : 3, RING = NSTAGE * STAGE;
     static constexpr int PPW = PC * CP / DW;                                      // DMA pieces per DMA wave and stage
     static constexpr int RED0 = (CP - 1) * TT * ND * 1024;                        // partial accumulators of the parities > 0 (aliases the ring)
     static_assert(D % 64 == 0 && (PC * CP) % DW == 0, "whole pieces per DMA wave");
     static_assert(RED0 <= RING && TT * 3 * D * 4 <= RING, "reduction buffers reuse the ring");
-    static_assert(2 * PPW < 64, "vmcnt immediates");
+    static_assert((NSTAGE - 2) * PPW < 64, "vmcnt immediates");
 };
 // tile shape used for width D when the tile is not chosen per M (D = 192: <12, 1> / <3, 2>)
 template <int D> struct WideTile { static constexpr int TT = D == 256 ? 8 : 6; };
@@ -139,7 +144,9 @@ __device__ __forceinline__ void dma_ring(int dw, int nc, char* ring, Issue issue
     for (int s = 0; s < LOOK && s < nst; ++s) stage(s);
     for (int s = 0; s < nst; ++s) {
         const int ahead = min(LOOK - 1, nst - 1 - s);         // stages that may remain in flight (loads retire in order)
-        if (ahead >= 2) wait_vmcnt<2 * Cf::PPW>();
+        if (ahead >= 4) wait_vmcnt<(LOOK >= 5 ? 4 : 0) * Cf::PPW>();
+        else if (ahead == 3) wait_vmcnt<(LOOK >= 4 ? 3 : 0) * Cf::PPW>();
+        else if (ahead == 2) wait_vmcnt<(LOOK >= 3 ? 2 : 0) * Cf::PPW>();
         else if (ahead == 1) wait_vmcnt<Cf::PPW>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                         // stage s landed; every compute wave is done with stage s - 1
@@ -396,7 +403,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
 // D != 192: no CS buffer (3 ring stages of 32 / 48 KiB leave no room for [TT][mlp] floats): every wave writes its column sums straight to
 // cs_part, one partial row per (tile, wave) — the reduce that follows takes TT times more rows.
 template <int D, int TT, int CP> struct MlpBwdLayout {
-    static constexpr bool CS_LDS = D == 192 && !TileCfg<D, TT, CP>::HALF;
+    static constexpr bool CS_LDS = D == 192 && !TileCfg<D, TT, CP>::HALF && (CP > 1 || T192_NS_TALL <= 4);
     static constexpr int RING = 0, CS = TileCfg<D, TT, CP>::RING;
     static size_t total(int mlp) { return (size_t)CS + (CS_LDS ? (size_t)TT * mlp * 4 : 0) + D * 4; }
 };
@@ -1125,11 +1132,12 @@ int m3l_mlp_t192_tiles(int D, int M) { return cdiv(M, tile_rows(D, M)); }
 // partial rows of the fc1 bias gradient: one per tile at D = 192 (summed over the tile's waves in LDS), one per (tile, wave) otherwise
 int m3l_mlp_t192_cs_rows(int D, int M) {
     const int tt = tile_rows(D, M) / 16;
-    return m3l_mlp_t192_tiles(D, M) * ((D == 192 && tt != 6) ? 1 : tt);
+    const bool cs_lds = D == 192 && tt != 6 && (tt == 3 || T192_NS_TALL <= 4);      // = MlpBwdLayout::CS_LDS of the tile shape in use
+    return m3l_mlp_t192_tiles(D, M) * (cs_lds ? 1 : tt);
 }
 
 template <typename K> static int lds_attr(K kern, size_t bytes) {
-    M3L_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    M3L_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(bytes, (size_t)160 * 1024)));
     return 0;
 }
 // one-time dynamic-LDS opt-in per kernel instantiation (the launchers below call it through a function-local static)
@@ -1196,6 +1204,7 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
     ProfScope prof("mlp_t192_bwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 4.0 + Dm * 12.0 + mlp * 4.0));
     T192_DISPATCH(Dm, tt, {
         LDS_ONCE((mlp_t192_bwd_kernel<D, TT, CP>), (MlpBwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
+        M3L_CHECK((MlpBwdLayout<D, TT, CP>::total(mlp)) <= (size_t)160 * 1024, "mlp_t192_bwd: %zu bytes of LDS", (MlpBwdLayout<D, TT, CP>::total(mlp)));
         mlp_t192_bwd_kernel<D, TT, CP><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
             (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t, cs_part,
             ln_part);

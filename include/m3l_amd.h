@@ -227,10 +227,15 @@ typedef struct m3l_cnn_cfg {
     int tactile;             /* 0: image stem (conv3 4/2/1), 1: tactile stem (conv3 3/1/1) */
     int dtype;
 } m3l_cnn_cfg;
+/* 1 (default): the bf16 stems of dim 64 / 128 / 256 run their three Conv2d + ReLU as direct (implicit-GEMM) convolutions (conv.hip: input
+ * patch of an 8 x 8 output tile staged once in LDS, no column matrix); 0: im2col + GEMM everywhere.  env M3L_DIRECT_CONV.  Set it before a
+ * forward and keep it until its backward has run (the workspace layout depends on it).  Returns the previous setting. */
+int m3l_set_direct_conv(int on);
 size_t m3l_earlycnn_ws_bytes(const m3l_cnn_cfg* c, int B, int nsrc);
 int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* srcs, const void* const* tensors, void* ws, float* out,
                      void* stream);
-int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const void* const* tensors, void* ws, const float* dout,
+/* srcs: the same input frames as the forward (the direct convolutions of the bf16 path keep no column matrix and read them again) */
+int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* srcs, const void* const* tensors, void* ws, const float* dout,
                      float* const* grads, void* stream);
 /* stem tokens -> encoder tokens: + modality embedding + sincos position (pretrain_models.py:202-216); tensors {mod_emb, pos_img, pos_tac} */
 size_t m3l_tokens_assemble_ws_bytes(const m3l_geom* g, int D);

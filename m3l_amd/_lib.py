@@ -45,6 +45,7 @@ _SIGS = {
     "m3l_set_attn_phase_buffer": (None, [c_p]),
     "m3l_set_enc_mega": (c_i, [c_i]),
     "m3l_set_drop_h": (c_i, [c_i]),
+    "m3l_set_direct_conv": (c_i, [c_i]),
     "m3l_set_t192": (c_i, [c_i]),
     "m3l_set_t192_tt": (c_i, [c_i]),
     "m3l_set_defer_join": (c_i, [c_i]),
@@ -88,7 +89,7 @@ _SIGS = {
     "m3l_mae_step_bwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(CommPlan), c_p]),
     "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
     "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_tokens_assemble_ws_bytes": (c_sz, [C.POINTER(Geom), c_i]),
     "m3l_tokens_assemble_fwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "m3l_tokens_assemble_bwd": (c_i, [C.POINTER(Geom), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

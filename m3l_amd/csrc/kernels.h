@@ -214,6 +214,18 @@ struct ConvSrc {
 };
 int m3l_im2col(int dtype, const ConvSrc* src, int Bsrc, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad, void* col,
                hipStream_t st);
+// direct (implicit-GEMM) convolutions of the EarlyCNN stem (conv.hip), bf16
+int m3l_conv_direct_supported(int dtype, int Ci, int Co, int KH, int S, int P, int first_layer);
+size_t m3l_conv_wf_elems(int Ci, int Co, int KH);
+size_t m3l_conv_wd_elems(int Ci, int Co, int KH, int S);
+size_t m3l_conv_wgrad_slab_elems(int B, int Ci, int H, int W, int Co, int KH, int S, int P);
+int m3l_conv_prep(const float* W, int Ci, int Co, int KH, int S, void* Wf, void* Wd, hipStream_t st);
+int m3l_conv_fwd(const ConvSrc* src, int Bsrc, int B, int Ci, int H, int W, int Co, int KH, int S, int P, const void* Wf, const float* bias,
+                 void* out, hipStream_t st);
+int m3l_conv_wgrad(const ConvSrc* src, int Bsrc, int B, int Ci, int H, int W, int Co, int KH, int S, int P, const void* dY, float* slab,
+                   float* dW, hipStream_t st);
+int m3l_conv_dgrad(const void* dY, int B, int Ci, int H, int W, int Co, int KH, int S, int P, const void* Wd, const void* act, void* dX,
+                   hipStream_t st);
 int m3l_col2im_relu(int dtype, const void* dcol, int Btot, int Ci, int H, int W, int KH, int S, int P, int OH, int OW, int Kpad,
                     const void* act, void* dX, hipStream_t st);
 int k_tokens_assemble(const float* img_tok, const float* tac_tok, int B, int D, int n_img, int n_tac, int k, const float* mod,

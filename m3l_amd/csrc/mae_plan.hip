@@ -338,7 +338,7 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
 // =================================================================================================================
 extern "C" {
 
-int m3l_version(void) { return 200; }
+int m3l_version(void) { return 300; }
 
 // diagnostic switch (bench.py's stand-alone roofline figure, PMC passes): 1 = every weight gradient on the caller's stream
 int m3l_set_wgrad_inline(int on) {
@@ -1248,9 +1248,27 @@ struct CnnWs {
     ConvL L[4];
     void *col[3], *act[3], *w[4], *wT[4];
     void *dout_t, *dpreA, *dpreB, *dcol;
+    void *wf[3], *wd[3];     // direct convolutions (conv.hip): forward / weight-gradient and input-gradient weight copies
+    float* slab;             // ... and the weight-gradient partial sums
+    bool direct;
     float* scratch;
     size_t scratch_b, total;
 };
+// direct (implicit-GEMM) convolutions for the three strided / 3x3 layers of the stem instead of im2col + GEMM: bf16, the stems of
+// dim 64 / 128 / 256; env M3L_DIRECT_CONV=0 keeps the im2col path (A/B, and the reference point of the parity tests)
+int g_direct_conv = -1;
+bool cnn_direct(const m3l_cnn_cfg* c) {
+    if (g_direct_conv < 0) g_direct_conv = getenv("M3L_DIRECT_CONV") ? (atoi(getenv("M3L_DIRECT_CONV")) > 0 ? 1 : 0) : 1;
+    if (!g_direct_conv || c->dtype != 1) return false;
+    const int D = c->dim, co[3] = {D / 8, D / 4, D / 2};
+    int ci = c->in_channels;
+    for (int l = 0; l < 3; ++l) {
+        const bool k3 = l == 2 && c->tactile;
+        if (!m3l_conv_direct_supported(c->dtype, ci, co[l], k3 ? 3 : 4, k3 ? 1 : 2, 1, l == 0)) return false;
+        ci = co[l];
+    }
+    return true;
+}
 CnnWs cnn_layout(const m3l_cnn_cfg* c, int Btot, void* ws) {
     Arena a(ws);
     CnnWs w;
@@ -1271,22 +1289,30 @@ CnnWs cnn_layout(const m3l_cnn_cfg* c, int Btot, void* ws) {
         ci = L.Co; H = L.OH; W = L.OW;
     }
     const size_t e = esz(c->dtype);
-    size_t max_pre = 0, max_col = 0;
+    size_t max_pre = 0, max_col = 0, max_slab = 0;
+    w.direct = cnn_direct(c);
     for (int l = 0; l < 4; ++l) {
         const ConvL& L = w.L[l];
         w.w[l] = a.take((size_t)L.Co * L.Kpad * e);
         w.wT[l] = a.take((size_t)L.Kpad * L.Co * e);
         if (l < 3) {
-            w.col[l] = a.take((size_t)L.M * L.Kpad * e);
+            w.col[l] = w.direct ? nullptr : a.take((size_t)L.M * L.Kpad * e);       // the column matrices exist only on the im2col path
             w.act[l] = a.take((size_t)L.M * L.Co * e);
             max_col = std::max(max_col, (size_t)L.M * L.Kpad);
+            w.wf[l] = w.wd[l] = nullptr;
+            if (w.direct) {
+                w.wf[l] = a.take(m3l_conv_wf_elems(L.Ci, L.Co, L.KH) * 2);
+                if (l) w.wd[l] = a.take(m3l_conv_wd_elems(L.Ci, L.Co, L.KH, L.S) * 2);
+                max_slab = std::max(max_slab, m3l_conv_wgrad_slab_elems(Btot, L.Ci, L.H, L.W, L.Co, L.KH, L.S, L.P));
+            }
         }
         max_pre = std::max(max_pre, (size_t)L.M * L.Co);
     }
     w.dout_t = a.take((size_t)w.L[3].M * D * e);
     w.dpreA = a.take(max_pre * e);
     w.dpreB = a.take(max_pre * e);
-    w.dcol = a.take(max_col * e);
+    w.dcol = w.direct ? nullptr : a.take(max_col * e);
+    w.slab = w.direct ? reinterpret_cast<float*>(a.take(max_slab * sizeof(float))) : nullptr;
     std::vector<std::pair<int, int>> shapes;
     long Mmax = 1;
     for (int l = 0; l < 4; ++l) { shapes.push_back({w.L[l].Co, w.L[l].Kpad}); Mmax = std::max(Mmax, w.L[l].M); }
@@ -1305,6 +1331,13 @@ int check_cnn(const m3l_cnn_cfg* c, int B, int nsrc) {
     return 0;
 }
 }  // namespace
+
+int m3l_set_direct_conv(int on) {
+    if (g_direct_conv < 0) g_direct_conv = getenv("M3L_DIRECT_CONV") ? (atoi(getenv("M3L_DIRECT_CONV")) > 0 ? 1 : 0) : 1;
+    const int old = g_direct_conv;
+    g_direct_conv = on ? 1 : 0;
+    return old;
+}
 
 size_t m3l_earlycnn_ws_bytes(const m3l_cnn_cfg* c, int B, int nsrc) {
     if (check_cnn(c, B, nsrc)) return 0;
@@ -1331,6 +1364,14 @@ int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* 
     cs.nsrc = nsrc; cs.nchw = 1;
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = w.L[l];
+        if (w.direct) {
+            // direct convolution (conv.hip): the input patch of an 8 x 8 output tile staged once in LDS, no column matrix
+            if (m3l_conv_prep((const float*)tensors[2 * l], L.Ci, L.Co, L.KH, L.S, w.wf[l], w.wd[l], st)) return 1;
+            if (m3l_conv_fwd(&cs, B, Btot, L.Ci, L.H, L.W, L.Co, L.KH, L.S, L.P, w.wf[l], (const float*)tensors[2 * l + 1], w.act[l], st)) return 1;
+            memset(&cs, 0, sizeof(cs));
+            cs.src[0] = w.act[l]; cs.nsrc = 1; cs.nchw = 0;
+            continue;
+        }
         if (m3l_im2col(dt, &cs, l == 0 ? B : Btot, L.Ci, L.H, L.W, L.KH, L.S, L.P, L.OH, L.OW, L.Kpad, w.col[l], st)) return 1;
         GemmEpi e = epi0(L.Co);
         e.bias = (const float*)tensors[2 * l + 1];
@@ -1347,7 +1388,7 @@ int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* 
     return m3l_gemm_nt(dt, w.act[2], L3.Kpad, w.w[3], L3.Kpad, (int)L3.M, L3.Co, L3.Kpad, &e, st);
 }
 
-int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const void* const* tensors, void* ws, const float* dout,
+int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* srcs, const void* const* tensors, void* ws, const float* dout,
                      float* const* grads, void* stream) {
     if (check_cnn(c, B, nsrc)) return 1;
     (void)tensors;
@@ -1368,6 +1409,23 @@ int m3l_earlycnn_bwd(const m3l_cnn_cfg* c, int B, int nsrc, const void* const* t
     }
     for (int l = 2; l >= 0; --l) {
         const ConvL& L = w.L[l];
+        if (w.direct) {
+            M3L_CHECK(srcs != nullptr, "earlycnn_bwd: the direct convolutions read the stem's input frames again (srcs)");
+            ConvSrc cs;
+            memset(&cs, 0, sizeof(cs));
+            if (l == 0) {
+                for (int i = 0; i < nsrc; ++i) cs.src[i] = srcs[i];
+                cs.nsrc = nsrc; cs.nchw = 1;
+            } else {
+                cs.src[0] = w.act[l - 1]; cs.nsrc = 1; cs.nchw = 0;
+            }
+            if (m3l_conv_wgrad(&cs, B, Btot, L.Ci, L.H, L.W, L.Co, L.KH, L.S, L.P, dpre, w.slab, grads[2 * l], st)) return 1;
+            if (m3l_colsum(dt, dpre, (int)L.M, L.Co, L.Co, w.scratch, grads[2 * l + 1], 0, st)) return 1;
+            if (l == 0) break;
+            if (m3l_conv_dgrad(dpre, Btot, L.Ci, L.H, L.W, L.Co, L.KH, L.S, L.P, w.wd[l], w.act[l - 1], dnext, st)) return 1;
+            std::swap(dpre, dnext);
+            continue;
+        }
         if (m3l_gemm_tn(dt, dpre, L.Co, w.col[l], L.Kpad, (int)L.M, L.Co, L.Kpad, w.scratch, w.scratch_b, grads[2 * l], L.K, L.Co, L.K, 0, st))
             return 1;
         if (m3l_colsum(dt, dpre, (int)L.M, L.Co, L.Co, w.scratch, grads[2 * l + 1], 0, st)) return 1;

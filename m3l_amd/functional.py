@@ -593,8 +593,8 @@ class EarlyCnnFn(torch.autograd.Function):
         dout = _f32c(dout)
         grads, direct = _grad_targets(ctx.sink, ctx.params)
         sink = ctx.sink if direct else None
-        L.check(L.lib().m3l_earlycnn_bwd(C.byref(cfg), B, nsrc, L.ptr_array(tens), L.ptr(ws), L.ptr(dout), L.ptr_array(grads),
-                                         _stream()), "m3l_earlycnn_bwd")
+        L.check(L.lib().m3l_earlycnn_bwd(C.byref(cfg), B, nsrc, L.ptr_array(srcs), L.ptr_array(tens), L.ptr(ws), L.ptr(dout),
+                                         L.ptr_array(grads), _stream()), "m3l_earlycnn_bwd")
         _done(sink)
         return (None, None, None) + _returned(sink, grads)
 

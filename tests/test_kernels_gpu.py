@@ -229,3 +229,47 @@ def test_fusion_mlp_linear_act(dev, M, K, N):
     assert torch.equal(cat, torch.cat((a, c), -1))
     (ga,) = torch.autograd.grad((cat * cat).sum(), (a,))
     assert torch.equal(ga, 2 * a.detach())
+
+
+@pytest.mark.parametrize("dim,C,hw,tactile,B,nsrc", [(64, 3, 32, False, 3, 1), (64, 3, 16, True, 2, 2), (128, 6, 64, False, 2, 1), (256, 12, 64, False, 3, 1),
+                                                     (256, 12, 32, True, 2, 2), (128, 3, 40, False, 2, 1), (256, 3, 24, True, 1, 3)])
+def test_direct_conv_stem_vs_im2col_and_torch(dev, dim, C, hw, tactile, B, nsrc):
+    """conv.hip (direct / implicit-GEMM convolutions of the EarlyCNN stem, models/pretrain_models.py:37-56) against the im2col + GEMM path
+    (m3l_set_direct_conv(0)) and against torch's Conv2d in fp64: stem outputs, every weight / bias gradient; output sizes that are not
+    multiples of the 8 x 8 tile (40 -> 20 / 10 / 5, 24 -> 12 / 6 / 6), 1-3 sources sharing the stem, 3 / 6 / 12 input channels."""
+    from m3l_amd.pretrain_models import EarlyCNN
+    torch.manual_seed(dim + hw)
+    stem = EarlyCNN(C, dim, key="tactile" if tactile else "image").to(dev)
+    g = torch.Generator().manual_seed(hw)
+    xs = [torch.rand(B, C, hw, hw, generator=g).to(dev) for _ in range(nsrc)]
+    res = {}
+    for direct in (0, 1):
+        old = L.lib().m3l_set_direct_conv(direct)
+        try:
+            stem.zero_grad(set_to_none=True)
+            out = stem.run(xs, "bf16")
+            cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            (out * cot).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            L.lib().m3l_set_direct_conv(old)
+        res[direct] = (out.detach().clone(), {n: p.grad.clone() for n, p in stem.named_parameters()})
+    # fp64 torch reference
+    ref = EarlyCNN(C, dim, key="tactile" if tactile else "image").double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in stem.state_dict().items()})
+    xr = torch.cat([x.cpu().double() for x in xs], 0)
+    h = torch.relu(ref.conv1(xr)); h = torch.relu(ref.conv2(h)); h = torch.relu(ref.conv3(h)); y = ref.conv4(h)
+    yr = y.flatten(2).transpose(1, 2)                       # (nsrc B, h w, dim): tokens, source-major
+    (yr * cot.cpu().double()).sum().backward()
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max()) / max(1e-9, float(b.abs().max()))      # noqa: E731
+    worst = {}
+    for direct in (0, 1):
+        out, gr = res[direct]
+        worst[direct] = max([("out", rel(out, yr.detach()))] + [(n, rel(gr[n], p.grad)) for n, p in ref.named_parameters()], key=lambda t: t[1])
+    # direct vs im2col: the same bf16 operands and roundings between layers, different accumulation order only
+    dvi = max([("out", rel(res[1][0], res[0][0].double().cpu()))] + [(n, rel(res[1][1][n], res[0][1][n].double().cpu())) for n in res[0][1]],
+              key=lambda t: t[1])
+    print(f"\n[conv] dim={dim} C={C} hw={hw} tactile={tactile}: worst vs fp64 torch im2col {worst[0]}, direct {worst[1]}; direct vs im2col {dvi}")
+    # bf16 through four layers against fp64: the direct path must be as close to the exact result as the im2col path is (x 1.5 + slack)
+    assert worst[1][1] <= max(0.1, 1.5 * worst[0][1]), worst
+    assert dvi[1] <= 0.08, dvi

@@ -629,24 +629,48 @@ __device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, 
 // t / d by one multiply: m = floor(2^32 / d) + 1 makes (t * m) >> 32 exact while t * d < 2^32 (here t < 2560, d <= 2560).  A patch
 // element otherwise costs two ~35-instruction integer divisions — at the 2352-wide patches of cfg 5 that arithmetic, not the memory,
 // set the time of the patch kernels (mse 104 us for 120 MB).
+// Walking order of the lanes over a patch (workgroup-uniform): IMAGE order for few channels (C < 6: P consecutive lanes read P consecutive
+// pixels of one image row, the patch vector is touched with stride C), PATCH order for many (frame-stacked inputs, C = 12: the lanes follow
+// the patch vector e = (p1 P + p2) C + c itself — pred / dpred / xn rows are read and written as whole 256-byte lines and the image is
+// touched in C runs of 64 / C consecutive pixels; in image order every wave load of the 2352-wide patch vector of cfg 5 touched 48
+// cache lines).
 struct PatchDiv {
-    unsigned m_pp, m_p;
-    int pp;
+    unsigned m_pp, m_p, m_c, m_cp;
+    int pp, cp, by_patch;
 };
-__device__ __forceinline__ PatchDiv patch_div(const PatchGroup& pg) {
+__device__ __forceinline__ PatchDiv patch_div(const PatchGroup& pg, bool allow_patch_order = false) {
     PatchDiv d;
     d.pp = pg.P * pg.P;
+    d.cp = pg.C * pg.P;
+    // measured at cfg 5 (C = 12, 14 x 14 patches): the loss kernel 103 -> 54 us in patch order; the patch-LayerNorm kernels, whose lanes keep
+    // 40 elements each in registers, 59 -> 72 us (backward) and 33 -> 36 us: they stay in image order
+    d.by_patch = allow_patch_order && pg.C >= 6;
     d.m_pp = 0xFFFFFFFFu / (unsigned)d.pp + 1u;
     d.m_p = 0xFFFFFFFFu / (unsigned)pg.P + 1u;
+    d.m_c = 0xFFFFFFFFu / (unsigned)pg.C + 1u;
+    d.m_cp = 0xFFFFFFFFu / (unsigned)d.cp + 1u;
     return d;
 }
+// the t-th element of the walk and its patch-vector index e
 __device__ __forceinline__ float patch_elem_t(const PatchGroup& pg, const PatchDiv& dv, int b, int s, int ph, int pw, int t, int& e) {
-    const int c = (int)__umulhi((unsigned)t, dv.m_pp), rem = t - c * dv.pp;
-    const int p1 = (int)__umulhi((unsigned)rem, dv.m_p), p2 = rem - p1 * pg.P;
-    e = rem * pg.C + c;
+    int c, p1, p2;
+    if (dv.by_patch) {
+        p1 = (int)__umulhi((unsigned)t, dv.m_cp);
+        const int rem = t - p1 * dv.cp;
+        p2 = (int)__umulhi((unsigned)rem, dv.m_c);
+        c = rem - p2 * pg.C;
+        e = t;
+    } else {
+        c = (int)__umulhi((unsigned)t, dv.m_pp);
+        const int rem = t - c * dv.pp;
+        p1 = (int)__umulhi((unsigned)rem, dv.m_p);
+        p2 = rem - p1 * pg.P;
+        e = rem * pg.C + c;
+    }
     return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
 }
 __device__ __forceinline__ int patch_index_t(const PatchGroup& pg, const PatchDiv& dv, int t) {
+    if (dv.by_patch) return t;
     const int c = (int)__umulhi((unsigned)t, dv.m_pp);
     return (t - c * dv.pp) * pg.C + c;
 }
@@ -1025,7 +1049,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     __shared__ float red[WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
-    const PatchDiv dv = patch_div(pg);
+    const PatchDiv dv = patch_div(pg, true);
     float acc = 0.f;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         int b, s, ph, pw, local;

@@ -1130,7 +1130,11 @@ int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out,
 
 // number of partial rows [G][3 D] one ln_bwd launch writes
 int m3l_ln_bwd_blocks(int M) {
-    int G = cdiv(M, 4 * WPB);                    // >= 4 rows per wave; up to 8 workgroups per CU
+    // rows per wave: 4 for large M (fewer partial rows to reduce), down to 1 for the short stacks of cfg 4 / cfg 5 (M = 2 k .. 10 k rows: a
+    // wave's rows are a chain of dependent load -> reduce -> load -> reduce -> store steps of ~3 us each; env M3L_LN_ROWS_PER_WAVE forces it)
+    static const int forced = getenv("M3L_LN_ROWS_PER_WAVE") ? atoi(getenv("M3L_LN_ROWS_PER_WAVE")) : 0;
+    const int rpw = forced > 0 ? forced : (M >= 12288 ? 4 : std::max(1, M / 4096));
+    int G = cdiv(M, rpw * WPB);                  // up to 8 workgroups per CU
     if (G > 2048) G = 2048;
     return G < 1 ? 1 : G;
 }

@@ -13,7 +13,9 @@ def timeit(fn, iters=50, warm=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 print("shape (M,N,K)            ours us   hipBLASLt us   ratio")
-for (M, N, K) in [(12288, 576, 192), (12288, 192, 192), (12288, 768, 192), (12288, 192, 768), (12288, 192, 576),
+CFG4 = [(7232, 1152, 384), (7232, 384, 384), (7232, 1536, 384), (7232, 384, 1536), (7232, 384, 1152),
+        (5120, 768, 256), (5120, 256, 256), (5120, 1024, 256), (5120, 256, 1024)]      # cfg 4 / cfg 5 encoder (B = 64), M3L default encoder (B = 512)
+for (M, N, K) in (CFG4 if "--wide" in sys.argv else []) + [(12288, 576, 192), (12288, 192, 192), (12288, 768, 192), (12288, 192, 768), (12288, 192, 576),
                   (49152, 576, 192), (49152, 192, 192), (49152, 768, 192), (49152, 192, 768), (49152, 192, 576)]:
     A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16()
     ot = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

@@ -182,6 +182,10 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     zd = fmaf(zd, x2, M3L_GF_A);
     return fmaf((x * s) * (1.0f - s), zd, s);
 }
+// the GELU of a compute type: erf form in fp32, the fitted form in bf16 (every bf16 kernel, GEMM epilogues included: at M of a few
+// thousand rows the fc1 / d_fc2 epilogues are VALU-bound on it)
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_f(x); }
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_fast(x) : gelu_grad_f(x); }
 
 // ---- host side -------------------------------------------------------------------------------------
 void m3l_set_error(const char* fmt, ...);

@@ -619,9 +619,13 @@ __device__ __forceinline__ void patch_locate(const PatchGroup& pg, const int64_t
     ph = pidx / gw;
     pw = pidx % gw;
 }
-__device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, int ph, int pw, int e) {
-    const int c = e % pg.C, p2 = (e / pg.C) % pg.P, p1 = e / (pg.C * pg.P);
-    return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
+// first pixel of channel 0 of the patch (the source pointer is picked ONCE per row: pg.src[s] with a run-time s is a load from a
+// private copy of the argument struct, and per element it was a dependent round trip in front of every gather)
+__device__ __forceinline__ const float* patch_base(const PatchGroup& pg, int b, int s, int ph, int pw) {
+    const float* src = pg.src[0];
+#pragma unroll
+    for (int i = 1; i < M3L_MAX_SENSORS; ++i) src = (s == i) ? pg.src[i] : src;
+    return src + ((long)b * pg.C * pg.H + ph * pg.P) * pg.W + pw * pg.P;
 }
 // The t-th element of a patch in IMAGE order (c, p1, p2 with p2 fastest) and its patch-vector index e.  Kernels that walk a
 // patch with consecutive lanes use this order: P consecutive lanes read P consecutive pixels of one image row (one 4 P-byte
@@ -629,151 +633,170 @@ __device__ __forceinline__ float patch_elem(const PatchGroup& pg, int b, int s, 
 // t / d by one multiply: m = floor(2^32 / d) + 1 makes (t * m) >> 32 exact while t * d < 2^32 (here t < 2560, d <= 2560).  A patch
 // element otherwise costs two ~35-instruction integer divisions — at the 2352-wide patches of cfg 5 that arithmetic, not the memory,
 // set the time of the patch kernels (mse 104 us for 120 MB).
-// Walking order of the lanes over a patch (workgroup-uniform): IMAGE order for few channels (C < 6: P consecutive lanes read P consecutive
-// pixels of one image row, the patch vector is touched with stride C), PATCH order for many (frame-stacked inputs, C = 12: the lanes follow
-// the patch vector e = (p1 P + p2) C + c itself — pred / dpred / xn rows are read and written as whole 256-byte lines and the image is
-// touched in C runs of 64 / C consecutive pixels; in image order every wave load of the 2352-wide patch vector of cfg 5 touched 48
-// cache lines).
+// The lanes always walk a patch in IMAGE order; what has to be read or written in PATCH-VECTOR order beside it (xn, dxn, pred, dpred,
+// gamma, beta) goes through an LDS copy of the patch in patch-vector order: the gather scatters into it (ds_write_b32, stride C), and a
+// second pass reads it back as 16-byte pieces next to fully coalesced 16-byte global accesses.  (Walking the patch vector with stride C
+// straight in global memory made every wave store of cfg 5's 2352-wide bf16 rows touch 12+ cache lines: patch_ln 34 us for 1920 rows.)
 struct PatchDiv {
-    unsigned m_pp, m_p, m_c, m_cp;
-    int pp, cp, by_patch;
+    unsigned m_pp, m_p;
+    int pp;
 };
-__device__ __forceinline__ PatchDiv patch_div(const PatchGroup& pg, bool allow_patch_order = false) {
+__device__ __forceinline__ PatchDiv patch_div(const PatchGroup& pg) {
     PatchDiv d;
     d.pp = pg.P * pg.P;
-    d.cp = pg.C * pg.P;
-    // measured at cfg 5 (C = 12, 14 x 14 patches): the loss kernel 103 -> 54 us in patch order; the patch-LayerNorm kernels, whose lanes keep
-    // 40 elements each in registers, 59 -> 72 us (backward) and 33 -> 36 us: they stay in image order
-    d.by_patch = allow_patch_order && pg.C >= 6;
     d.m_pp = 0xFFFFFFFFu / (unsigned)d.pp + 1u;
     d.m_p = 0xFFFFFFFFu / (unsigned)pg.P + 1u;
-    d.m_c = 0xFFFFFFFFu / (unsigned)pg.C + 1u;
-    d.m_cp = 0xFFFFFFFFu / (unsigned)d.cp + 1u;
     return d;
 }
-// the t-th element of the walk and its patch-vector index e
-__device__ __forceinline__ float patch_elem_t(const PatchGroup& pg, const PatchDiv& dv, int b, int s, int ph, int pw, int t, int& e) {
-    int c, p1, p2;
-    if (dv.by_patch) {
-        p1 = (int)__umulhi((unsigned)t, dv.m_cp);
-        const int rem = t - p1 * dv.cp;
-        p2 = (int)__umulhi((unsigned)rem, dv.m_c);
-        c = rem - p2 * pg.C;
-        e = t;
-    } else {
-        c = (int)__umulhi((unsigned)t, dv.m_pp);
-        const int rem = t - c * dv.pp;
-        p1 = (int)__umulhi((unsigned)rem, dv.m_p);
-        p2 = rem - p1 * pg.P;
-        e = rem * pg.C + c;
-    }
-    return pg.src[s][(((long)b * pg.C + c) * pg.H + ph * pg.P + p1) * pg.W + pw * pg.P + p2];
-}
-__device__ __forceinline__ int patch_index_t(const PatchGroup& pg, const PatchDiv& dv, int t) {
-    if (dv.by_patch) return t;
+// offset (from patch_base) of the t-th element of the walk and its patch-vector index e
+__device__ __forceinline__ int patch_off_t(const PatchGroup& pg, const PatchDiv& dv, int t, int& e) {
     const int c = (int)__umulhi((unsigned)t, dv.m_pp);
-    return (t - c * dv.pp) * pg.C + c;
+    const int rem = t - c * dv.pp;
+    const int p1 = (int)__umulhi((unsigned)rem, dv.m_p);
+    const int p2 = rem - p1 * pg.P;
+    e = rem * pg.C + c;
+    return (c * pg.H + p1) * pg.W + p2;
 }
-
-// gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
-// NV = elements per lane: 16 for patch dims <= 1024, 40 for <= 2560 (cfg 5: 14x14 patches of 4 stacked RGB frames = 2352)
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
-                                                         int rows, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, T* __restrict__ xn, int pdpad) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int pd = pg.C * pg.P * pg.P;
-    const PatchDiv dv = patch_div(pg);
-    int b, s, ph, pw, local;
-    patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+// gather the patch of one row into `my` (patch-vector order) and return its LayerNorm statistics.  All NV gathers of a lane are requested
+// before the first is used (indices past the patch clamp to its last element: a load under `if (t < pd)` sits in its own basic block with
+// its wait, and the 40 gathers of a 2352-wide patch were 40 dependent round trips: 36 us for 1920 rows).
+template <int NV>
+__device__ __forceinline__ void patch_stage_stats(const PatchGroup& pg, const PatchDiv& dv, const float* __restrict__ base, int lane, int pd,
+                                                  float eps, float* __restrict__ my, float& mean, float& rstd) {
     float v[NV];
     int ei[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = base[patch_off_t(pg, dv, min(lane + 64 * i, pd - 1), ei[i])];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int t = lane + 64 * i;
-        ei[i] = t;
-        v[i] = (t < pd) ? patch_elem_t(pg, dv, b, s, ph, pw, t, ei[i]) : 0.f;
+        if (lane + 64 * i < pd) my[ei[i]] = v[i];
+        else v[i] = 0.f;
         sum += v[i];
     }
-    const float mean = wave_sum(sum) / pd;
+    mean = wave_sum(sum) / pd;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int e = lane + 64 * i;
-        const float d = (e < pd) ? v[i] - mean : 0.f;
+        const float d = (lane + 64 * i < pd) ? v[i] - mean : 0.f;
         q += d * d;
     }
-    const float rstd = rsqrtf(wave_sum(q) / pd + eps);
+    rstd = rsqrtf(wave_sum(q) / pd + eps);
+}
+
+// gather + LayerNorm(pd) -> xn [rows, pdpad] (compute type; pad columns zeroed)
+// NV = elements per lane: 4 for patch dims <= 256 (cfg 2: 48), 16 for <= 1024, 40 for <= 2560 (cfg 5: 14x14 patches of 4 stacked RGB
+// frames = 2352); every lane requests all NV (clamped), so NV follows the patch dim
+// vec: pd, pdpad multiples of 4 and xn / gamma / beta aligned for 4-element accesses (host-checked)
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void patch_ln_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
+                                                         int rows, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, T* __restrict__ xn, int pdpad, int vec) {
+    __shared__ __attribute__((aligned(16))) float buf[WPB][NV * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x * WPB + wave;
+    const int pd = pg.C * pg.P * pg.P;
+    const PatchDiv dv = patch_div(pg);
+    float* my = buf[wave];
+    const bool live = row < rows;
+    float mean = 0.f, rstd = 0.f;
+    if (live) {
+        int b, s, ph, pw, local;
+        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+        patch_stage_stats<NV>(pg, dv, patch_base(pg, b, s, ph, pw), lane, pd, eps, my, mean, rstd);
+    }
+    __syncthreads();
+    if (!live) return;
+    T* out = xn + (long)row * pdpad;
+    if (vec) {
+        constexpr int NC = NV / 4;                 // pieces per lane: gamma / beta of all of them are requested up front
+        f32x4 gm[NC], bt[NC];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int t = lane + 64 * i, e = ei[i];
-        if (t < pd)
-            xn[(long)row * pdpad + e] = from_f32<T>((v[i] - mean) * rstd * gamma[e] + beta[e]);
-        else if (t < pdpad)
-            xn[(long)row * pdpad + t] = from_f32<T>(0.f);
+        for (int k = 0; k < NC; ++k) {
+            const int ec = min(4 * (lane + 64 * k), pd - 4);
+            gm[k] = load4(gamma + ec);
+            bt[k] = load4(beta + ec);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int e = 4 * (lane + 64 * k);
+            if (e < pdpad) {
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                if (e < pd) r = (*reinterpret_cast<const f32x4*>(my + e) - mean) * rstd * gm[k] + bt[k];
+                store4<T>(out + e, r);
+            }
+        }
+    } else {
+        for (int e = lane; e < pdpad; e += 64) out[e] = from_f32<T>(e < pd ? (my[e] - mean) * rstd * gamma[e] + beta[e] : 0.f);
     }
 }
 
-// backward of the first patch LayerNorm w.r.t. its affine parameters (the input is data): part[G][2*pd]
+// backward of the first patch LayerNorm w.r.t. its affine parameters (the input is data): part[G][2*pd].
+// A lane owns the same 4-element pieces of the patch vector for every row of its wave (NV / 4 pieces: 20 accumulator registers per
+// 256 elements); the four waves' sums meet in the patch buffers in a fixed order.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(PatchGroup pg, const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt,
                                                              int rows, float eps, const T* __restrict__ dxn, int pdpad,
-                                                             float* __restrict__ part) {
-    __shared__ float red[WPB][128];
+                                                             float* __restrict__ part, int vec) {
+    __shared__ __attribute__((aligned(16))) float buf[WPB][NV * 64];
+    constexpr int NC = NV / 4;
+    static_assert(NV % 4 == 0, "4-element pieces");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
     const PatchDiv dv = patch_div(pg);
-    float dg[NV], db[NV];
+    float* my = buf[wave];
+    f32x4 dg[NC], db[NC];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) dg[i] = db[i] = 0.f;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
-        int b, s, ph, pw, local;
-        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-        float v[NV];
-        int ei[NV];
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int t = lane + 64 * i;
-            ei[i] = t;
-            v[i] = (t < pd) ? patch_elem_t(pg, dv, b, s, ph, pw, t, ei[i]) : 0.f;
-            sum += v[i];
+    for (int k = 0; k < NC; ++k) dg[k] = db[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = blockIdx.x * WPB; r0 < rows; r0 += gridDim.x * WPB) {       // block-uniform trip count (barriers inside)
+        const int row = r0 + wave;
+        const bool live = row < rows;
+        float mean = 0.f, rstd = 0.f;
+        if (live) {
+            int b, s, ph, pw, local;
+            patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+            patch_stage_stats<NV>(pg, dv, patch_base(pg, b, s, ph, pw), lane, pd, eps, my, mean, rstd);
         }
-        const float mean = wave_sum(sum) / pd;
-        float q = 0.f;
+        __syncthreads();
+        if (live) {
+            const T* dr = dxn + (long)row * pdpad;
+            f32x4 d[NC];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            const float d = (e < pd) ? v[i] - mean : 0.f;
-            q += d * d;
-        }
-        const float rstd = rsqrtf(wave_sum(q) / pd + eps);
+            for (int k = 0; k < NC; ++k) {                                     // every piece of the row requested before the first is used
+                const int e = 4 * (lane + 64 * k);
+                if (vec) {
+                    d[k] = load4(dr + min(e, pd - 4));
+                } else {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (lane + 64 * i < pd) {
-                const float d = to_f32(dxn[(long)row * pdpad + ei[i]]);
-                dg[i] += d * (v[i] - mean) * rstd;
-                db[i] += d;
+                    for (int q = 0; q < 4; ++q) d[k][q] = to_f32(dr[min(e + q, pd - 1)]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int e = 4 * (lane + 64 * k);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                if (vec) {
+                    if (e < pd) a = *reinterpret_cast<const f32x4*>(my + e);
+                    else d[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (e + q < pd) a[q] = my[e + q];
+                        else d[k][q] = 0.f;
+                    }
+                }
+                dg[k] += d[k] * (a - mean) * rstd;
+                db[k] += d[k];
             }
         }
+        __syncthreads();                                                       // the buffers are refilled by the next row
     }
     float* out = part + (long)blockIdx.x * 2 * pd;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if (64 * i >= pd) break;
-        red[wave][lane] = dg[i];
-        red[wave][64 + lane] = db[i];
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) *reinterpret_cast<f32x4*>(my + 4 * (lane + 64 * k)) = pass ? db[k] : dg[k];
         __syncthreads();
-        if (wave == 0) {
-            const int t = lane + 64 * i;
-            if (t < pd) {
-                const int e = patch_index_t(pg, dv, t);
-                out[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-                out[pd + e] = red[0][64 + lane] + red[1][64 + lane] + red[2][64 + lane] + red[3][64 + lane];
-            }
-        }
+        for (int e = threadIdx.x; e < pd; e += 256) out[pass * pd + e] = buf[0][e] + buf[1][e] + buf[2][e] + buf[3][e];
         __syncthreads();
     }
 }
@@ -1041,44 +1064,74 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__
 }
 
 // masked-patch MSE (pretrain_models.py:260-262,327-340): pred [rows, pdpad] f32 vs raw target patches gathered by the
-// masked indices; part[G] = w * sum (pred - tgt)^2 ; dpred = 2 w (pred - tgt) in compute type (pad columns zero)
+// masked indices; part[G] = w * sum (pred - tgt)^2 ; dpred = 2 w (pred - tgt) in compute type (pad columns zero).
+// The target patch is gathered in image order into an LDS copy in patch-vector order (dynamic LDS: WPB x pdpad floats); pred, dpred and
+// target_out are then walked as 16-byte pieces (cfg 5, 7680 rows x 2352: 119 us one element at a time -> 104 -> 53 with the patch-order
+// walk of round 3 -> this form).
 template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, int pdpad, PatchGroup pg,
                                                     const int64_t* __restrict__ idx, int idx_ld, int j0, int cnt, int rows, float w,
-                                                    float* __restrict__ part, T* __restrict__ dpred, float* __restrict__ target_out) {
+                                                    float* __restrict__ part, T* __restrict__ dpred, float* __restrict__ target_out, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float mbuf[];
     __shared__ float red[WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pd = pg.C * pg.P * pg.P;
-    const PatchDiv dv = patch_div(pg, true);
+    const PatchDiv dv = patch_div(pg);
+    float* my = mbuf + (long)wave * pdpad;
     float acc = 0.f;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
-        int b, s, ph, pw, local;
-        patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
-        // four elements per lane in flight (loads first, then the stores: one element per iteration was a chain of dependent round
-        // trips, 119 us for the 7680 x 2352 patches of cfg 5); the per-lane sum keeps its order (t ascending)
-        for (int t0 = lane; t0 < pdpad; t0 += 256) {
-            float tv[4], pv[4];
-            int e[4];
+    for (int r0 = blockIdx.x * WPB; r0 < rows; r0 += gridDim.x * WPB) {       // block-uniform trip count (barriers inside)
+        const int row = r0 + wave;
+        const bool live = row < rows;
+        if (live) {
+            int b, s, ph, pw, local;
+            patch_locate(pg, idx, idx_ld, j0, cnt, row, b, s, ph, pw, local);
+            const float* base = patch_base(pg, b, s, ph, pw);
+            for (int tb = 0; tb < pd; tb += 512) {                            // eight gathers in flight per lane
+                const int t0 = tb + lane;
+                float tv[8];
+                int e[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + 64 * u;
-                e[u] = t;
-                tv[u] = pv[u] = 0.f;
-                if (t < pd) {
-                    tv[u] = patch_elem_t(pg, dv, b, s, ph, pw, t, e[u]);
-                    pv[u] = pred[(long)row * pdpad + e[u]];
+                for (int u = 0; u < 8; ++u) {
+                    if (tb + 64 * u >= pd) break;                              // wave-uniform
+                    const int t = t0 + 64 * u;
+                    tv[u] = base[patch_off_t(pg, dv, min(t, pd - 1), e[u])];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (tb + 64 * u >= pd) break;
+                    if (t0 + 64 * u < pd) my[e[u]] = tv[u];
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + 64 * u;
-                if (t >= pdpad) break;
-                const float d = t < pd ? pv[u] - tv[u] : 0.f;
-                if (t < pd && target_out) target_out[(long)row * pd + e[u]] = tv[u];
-                acc += d * d;
-                dpred[(long)row * pdpad + e[u]] = from_f32<T>(2.f * w * d);
+        }
+        __syncthreads();
+        if (live) {
+            const float* pr = pred + (long)row * pdpad;
+            T* dp = dpred + (long)row * pdpad;
+            if (vec) {
+#pragma unroll 4
+                for (int e = 4 * lane; e < pdpad; e += 256) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    if (e < pd) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(my + e);
+                        d = load4(pr + e) - t;
+                        if (target_out) store4<float>(target_out + (long)row * pd + e, t);
+                    }
+                    acc += d[0] * d[0];
+                    acc += d[1] * d[1];
+                    acc += d[2] * d[2];
+                    acc += d[3] * d[3];
+                    store4<T>(dp + e, d * (2.f * w));
+                }
+            } else {
+                for (int e = lane; e < pdpad; e += 64) {
+                    const float d = e < pd ? pr[e] - my[e] : 0.f;
+                    if (e < pd && target_out) target_out[(long)row * pd + e] = my[e];
+                    acc += d * d;
+                    dp[e] = from_f32<T>(2.f * w * d);
+                }
             }
         }
+        __syncthreads();
     }
     acc = wave_sum(acc);
     if (lane == 0) red[wave] = acc;
@@ -1090,6 +1143,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
 
 // =================================================================================================================
 static int ln_grid(int M) { return cdiv(M, WPB); }
+static bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
 int m3l_part_blocks(void) {
     static const int nb = [] {
         const char* e = getenv("M3L_PART_BLOCKS");
@@ -1394,12 +1448,14 @@ int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld
     if (check_pg(*pg)) return 1;
     const int rows = B * cnt;
     if (rows == 0) return 0;
-    const bool wide = pg->C * pg->P * pg->P > 64 * MAXV;
-#define PATCH_LN(T, NV) patch_ln_kernel<T, NV><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (T*)xn, pdpad)
+    const int pd_ = pg->C * pg->P * pg->P, esz = dtype == 1 ? 2 : 4;
+    const bool wide = pd_ > 64 * MAXV, tiny = pd_ <= 256;
+    const int vec = pd_ % 4 == 0 && pdpad % 4 == 0 && aligned_to(gamma, 16) && aligned_to(beta, 16) && aligned_to(xn, 4 * esz);
+#define PATCH_LN(T, NV) patch_ln_kernel<T, NV><<<ln_grid(rows), 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, gamma, beta, eps, (T*)xn, pdpad, vec)
     if (dtype == 1) {
-        if (wide) PATCH_LN(bf16, PATCH_NV_MAX); else PATCH_LN(bf16, MAXV);
+        if (wide) PATCH_LN(bf16, PATCH_NV_MAX); else if (tiny) PATCH_LN(bf16, 4); else PATCH_LN(bf16, MAXV);
     } else {
-        if (wide) PATCH_LN(float, PATCH_NV_MAX); else PATCH_LN(float, MAXV);
+        if (wide) PATCH_LN(float, PATCH_NV_MAX); else if (tiny) PATCH_LN(float, 4); else PATCH_LN(float, MAXV);
     }
 #undef PATCH_LN
     M3L_LAUNCH_CHECK();
@@ -1413,12 +1469,13 @@ int m3l_patch_ln_bwd(int dtype, const PatchGroup* pg, const int64_t* idx, int id
     if (rows == 0) return 0;
     const int pd = pg->C * pg->P * pg->P;
     const int G = part_grid(rows);
-    const bool wide = pd > 64 * MAXV;
-#define PATCH_LN_BWD(T, NV) patch_ln_bwd_kernel<T, NV><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const T*)dxn, pdpad, part_ws)
+    const bool wide = pd > 64 * MAXV, tiny = pd <= 256;
+    const int vec = pd % 4 == 0 && pdpad % 4 == 0 && aligned_to(dxn, 4 * (dtype == 1 ? 2 : 4));
+#define PATCH_LN_BWD(T, NV) patch_ln_bwd_kernel<T, NV><<<G, 256, 0, st>>>(*pg, idx, idx_ld, j0, cnt, rows, eps, (const T*)dxn, pdpad, part_ws, vec)
     if (dtype == 1) {
-        if (wide) PATCH_LN_BWD(bf16, PATCH_NV_MAX); else PATCH_LN_BWD(bf16, MAXV);
+        if (wide) PATCH_LN_BWD(bf16, PATCH_NV_MAX); else if (tiny) PATCH_LN_BWD(bf16, 4); else PATCH_LN_BWD(bf16, MAXV);
     } else {
-        if (wide) PATCH_LN_BWD(float, PATCH_NV_MAX); else PATCH_LN_BWD(float, MAXV);
+        if (wide) PATCH_LN_BWD(float, PATCH_NV_MAX); else if (tiny) PATCH_LN_BWD(float, 4); else PATCH_LN_BWD(float, MAXV);
     }
 #undef PATCH_LN_BWD
     M3L_LAUNCH_CHECK();
@@ -1539,10 +1596,15 @@ int m3l_mse(int dtype, const float* pred, int pdpad, const PatchGroup* pg, const
     const int pd = pg->C * pg->P * pg->P;
     const float w = weight / ((float)rows * (float)pd);
     const int G = part_grid(rows);
+    M3L_CHECK(pdpad >= pd, "mse: pdpad %d < patch dim %d", pdpad, pd);
+    const int vec = pd % 4 == 0 && pdpad % 4 == 0 && aligned_to(pred, 16) && aligned_to(dpred, 4 * (dtype == 1 ? 2 : 4)) &&
+                    (!target_out || aligned_to(target_out, 16));
+    const size_t lds = (size_t)WPB * pdpad * sizeof(float);
+    M3L_CHECK(lds <= 64 * 1024, "mse: padded patch dim %d too wide", pdpad);
     if (dtype == 1)
-        mse_kernel<bf16><<<G, 256, 0, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (bf16*)dpred, target_out);
+        mse_kernel<bf16><<<G, 256, lds, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (bf16*)dpred, target_out, vec);
     else
-        mse_kernel<float><<<G, 256, 0, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (float*)dpred, target_out);
+        mse_kernel<float><<<G, 256, lds, st>>>(pred, pdpad, *pg, idx, idx_ld, j0, cnt, rows, w, part_ws, (float*)dpred, target_out, vec);
     M3L_LAUNCH_CHECK();
     if (nblocks_out) *nblocks_out = G;
     return 0;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         for (int j = 0; j < 8; ++j) v[j] = v[j] * epi.alpha + bias[j];
         if (gelu_u) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(to_f32(gelu_u[o + j]));
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_t<T>(to_f32(gelu_u[o + j]));
         }
         if (out_pre) {
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         }
         if (epi.act == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            for (int j = 0; j < 8; ++j) v[j] = gelu_t<T>(v[j]);
         } else if (epi.act == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
                     for (int j = 0; j < 8; ++j) uu.v[j] = gelu_u[o + j];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(to_f32(uu.v[j]));
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_t<T>(to_f32(uu.v[j]));
             }
             if (f_out_pre) {
                 Frag<T> pk;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
             }
             if (f_act == 1) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                for (int j = 0; j < 8; ++j) v[j] = gelu_t<T>(v[j]);
             } else if (f_act == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);

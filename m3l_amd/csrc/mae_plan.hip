@@ -149,8 +149,8 @@ inline bool drop_h() {
     return g_drop_h == 1;
 }
 // which fused kernel (if any) computes the feed-forward half of a layer in the FORWARD — the same decisions as m3l_transformer_fwd below:
-// 0 = per-op GEMMs (h is the operand of the fc2 GEMM: always saved), 1 = per-sample block kernel (erf-form GELU), 2 = row-tiled kernel
-// (fitted GELU).  The backward reads it to know whether h exists and which GELU reproduces it.
+// 0 = per-op GEMMs (h is the operand of the fc2 GEMM: always saved), 1 = per-sample block kernel, 2 = row-tiled kernel
+// (both evaluate the fitted GELU, as every bf16 kernel does).  The backward reads it to know whether h exists and which GELU reproduces it.
 int fused_mlp_kind(const m3l_tf_cfg* c, int B, int n, bool fuse) {
     const int M = B * n, D = c->dim, mlp = c->mlp_dim, dt = c->dtype;
     if (fuse || dt != 1) return 0;
@@ -881,7 +881,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         // goes out as ONE grouped TN launch + one reduce on the side stream, overlapping the dgrad chains of the layers below
         {
             // dW2 = dx^T h; when the forward did not save h the kernel stages u and applies the GELU of the kernel that made it
-            const int hk = drop_h() ? fused_mlp_kind(c, B, n, fuse) : 0;
+            const int hk = (drop_h() && fused_mlp_kind(c, B, n, fuse)) ? 2 : 0;     // every bf16 kernel evaluates the fitted GELU (form 2)
             pend.push_back(TnProblem{w.dx_t[cur], hk ? L.u : L.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0, hk});
             pend.push_back(TnProblem{w.du[cur], L.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0});             // dW1 = du^T xn2
             pend.push_back(TnProblem{w.dqkv[cur], L.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0}); // dWqkv = dqkv^T xn1

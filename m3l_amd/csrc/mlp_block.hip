@@ -186,7 +186,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bf16 ub = (bf16)(acc[r] + bias);                    // pre-activation as the backward will read it
-                const bf16 hb = (bf16)gelu_f((float)ub);
+                const bf16 hb = (bf16)gelu_fast((float)ub);
                 const int off = (16 * rt + 4 * g + r) * Ly::HC_PITCH + (16 * ct + li) * 2;
                 *reinterpret_cast<bf16*>(US + off) = ub;
                 *reinterpret_cast<bf16*>(HS + off) = hb;
@@ -391,7 +391,7 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
             for (int r = 0; r < 4; ++r) {
                 const int off = (16 * rt + 4 * g + r) * Ly::HC_PITCH + (16 * ct + li) * 2;
                 const float uv = (float)*reinterpret_cast<const bf16*>(US + off);
-                const bf16 db_ = (bf16)(acc[r] * gelu_grad_f(uv));
+                const bf16 db_ = (bf16)(acc[r] * gelu_grad_fast(uv));
                 *reinterpret_cast<bf16*>(DS + off) = db_;
                 csum += (float)db_;
             }

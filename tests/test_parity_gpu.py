@@ -539,6 +539,16 @@ def test_cfg5_frame_stack4_patch_dim_2352():
                       B=2, C=12, hw_img=70, hw_tac=70, k=2, cfg=cfg)
 
 
+def test_odd_patch_dim_takes_the_element_wise_walk():
+    """7x7 RGB patches (patch dim 147, not a multiple of 4; tactile 5x5 = 75): the patch kernels' 16-byte walk of the patch vector does
+    not apply and the per-element form runs — same bounds against the oracle (pretrain_models.py:196-205,327-340)."""
+    cfg = O.OracleCfg(56, 30, 7, 5, 128, 1, 2, 256, 3, 2, 128, 1, 2, 0.75)
+    _parity_vs_oracle(dict(image_size=56, tactile_size=30, image_patch_size=7, tactile_patch_size=5, dim=128, depth=1, heads=2,
+                           mlp_dim=256, num_tactiles=2),
+                      dict(decoder_dim=128, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2),
+                      B=3, C=3, hw_img=56, hw_tac=30, k=2, cfg=cfg)
+
+
 def test_flat_adam_matches_torch_adam():
     """FlatAdam (one HIP launch over the flat parameter buffer) == torch.optim.Adam step for step (reference optimizer,
     ppo_mae.py:182-183), including weight decay."""

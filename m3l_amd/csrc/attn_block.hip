@@ -32,16 +32,8 @@ constexpr int AB_CW = 12;                 // compute waves: (column tile 0..3) x
 constexpr int AB_THREADS = 64 * (AB_CW + 1);   // + the DMA wave
 constexpr float AB_SCALE = 0.125f;        // dim_head ** -0.5, dim_head = 64
 
-// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), every lane of the row gets the total: four VALU-rate DPP steps, no
-// LDS crossbar.  The LayerNorms give each ROW to one 16-lane group (a wave works on 4 rows at a time) so their two reductions per
-// row cost 8 DPP adds instead of 12 dependent ds_bpermute shuffles — with one wave per SIMD nothing else hides that latency.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
-    return v;
-}
+// (row16_sum — common.cuh — gives each LayerNorm ROW to one 16-lane group: a wave works on 4 rows at a time, and their two reductions per
+// row cost 8 DPP adds instead of 12 dependent ds_bpermute shuffles — with one wave per SIMD nothing else hides that latency.)
 
 template <int KT> struct AbLayout {
     static constexpr int D = 64 * KT;

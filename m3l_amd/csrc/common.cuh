@@ -113,10 +113,23 @@ template <typename T> struct Chunk;
 template <> struct Chunk<bf16> { static constexpr int N = 8; };
 template <> struct Chunk<float> { static constexpr int N = 4; };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), every lane of the row gets the total: four VALU-rate DPP steps, no
+// LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
     return v;
+}
+// sum over the whole wave (call with every lane active), every lane gets the total: the four row totals meet through v_readlane (scalar
+// registers) instead of a chain of six ds_bpermute round trips through the LDS crossbar (~500 cycles; the one-row-per-wave LayerNorm kernels
+// do two to four of these in a row and nothing hides them)
+__device__ __forceinline__ float wave_sum(float v) {
+    const int r = __builtin_bit_cast(int, row16_sum(v));
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48));
+    return (a + b) + (c + d);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -40,7 +40,8 @@ __device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int e = 4 * (lane + 64 * i);
-        v[i] = (e < D) ? load4(xr + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = load4(xr + min(e, D - 4));          // clamped, not `if (e < D)`: every chunk is requested before the first is used
+        if (e >= D) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     mean = wave_sum(s) / D;
@@ -62,14 +63,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                        float* __restrict__ y32) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= M) return;
-    f32x4 v[MAXC];
+    f32x4 v[MAXC], gm[MAXC], bt[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {               // gamma / beta travel with the row, not after its statistics
+        const int ec = min(4 * (lane + 64 * i), D - 4);
+        gm[i] = load4(gamma + ec);
+        bt[i] = load4(beta + ec);
+    }
     float mean, rstd;
     row_stats<MAXC>(x + (long)row * D, D, lane, v, eps, mean, rstd);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int e = 4 * (lane + 64 * i);
         if (e < D) {
-            const f32x4 r = (v[i] - mean) * rstd * load4(gamma + e) + load4(beta + e);
+            const f32x4 r = (v[i] - mean) * rstd * gm[i] + bt[i];
             if (y) store4<TO>(y + (long)row * D + e, r);
             if (y32) store4<float>(y32 + (long)row * D + e, r);
         }
@@ -88,21 +95,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
     f32x4 dg[MAXC], db[MAXC], dc[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) dg[i] = db[i] = dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gm[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) gm[i] = load4(gamma + min(4 * (lane + 64 * i), D - 4));
     for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
-        f32x4 v[MAXC], gdy[MAXC];
+        // every operand of the row (x, dy, the residual gradient) is requested before the statistics: one memory round trip per row
+        // instead of three (loads under `if (e < D)` sit in their own basic blocks, each with its wait)
+        f32x4 v[MAXC], gdy[MAXC], dyv[MAXC], rs[MAXC];
+        const TD* dyr = dy + (long)row * D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ec = min(4 * (lane + 64 * i), D - 4);
+            dyv[i] = load4(dyr + ec);
+            rs[i] = dres ? load4(dres + (long)row * D + ec) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float mean, rstd;
         row_stats<MAXC>(x + (long)row * D, D, lane, v, eps, mean, rstd);
-        const TD* dyr = dy + (long)row * D;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int e = 4 * (lane + 64 * i);
             if (e < D) {
                 const f32x4 xh = (v[i] - mean) * rstd;
-                const f32x4 d = load4(dyr + e);
+                const f32x4 d = dyv[i];
                 dg[i] += d * xh;
                 db[i] += d;
-                const f32x4 gd = d * load4(gamma + e);
+                const f32x4 gd = d * gm[i];
                 gdy[i] = gd;
                 v[i] = xh;
                 s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
             const int e = 4 * (lane + 64 * i);
             if (e < D) {
                 f32x4 r = (gdy[i] - s1 - v[i] * s2) * rstd;
-                if (dres) r += load4(dres + (long)row * D + e);
+                if (dres) r += rs[i];
                 dc[i] += r;
                 if (dx_out) store4<float>(dx_out + (long)row * D + e, r);
                 if (dx_t_out) store4<TC>(dx_t_out + (long)row * D + e, r);

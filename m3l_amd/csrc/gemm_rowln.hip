@@ -27,14 +27,7 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16* p, f32x4 v) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// sum over the 16 lanes of a DPP row (lanes that share lane >> 4); every lane of the row gets the total
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
-    return v;
-}
+// (row16_sum: common.cuh)
 // sum over the 4 lanes that hold the same row (same lane & 15)
 __device__ __forceinline__ float col4_sum(float v) {
     v += __shfl_xor(v, 16, 64);

@@ -71,14 +71,60 @@ __global__ __launch_bounds__(AB_THREADS) void enc_fwd_mega_kernel(const float* _
 
 template <int KT> constexpr int mega_fwd_lds() { return AbLayout<KT>::TOTAL > MbLayout<KT>::TOTAL ? AbLayout<KT>::TOTAL : MbLayout<KT>::TOTAL; }
 
+// Backward of a GROUP of layers (the layers whose weight gradients go out as one grouped launch on the side stream) in one launch: per
+// layer the feed-forward backward body, then the attention backward body, top layer first.  Every tensor a body hands to the next one (the
+// running residual gradient dx, updated in place; dx1_t; dx_t of the layer below) is per-sample rows that this workgroup wrote itself.
+// The idea was that the backward runs beside the side stream's weight-gradient workgroups, and at every kernel boundary of the compute
+// stream the CUs that drain first are handed to those (each then holds its CU for its whole duration: no two of these workgroups fit one
+// CU) — fewer boundaries, fewer hand-overs.  Measured (round 3, A/B in one job): 64.3-64.4 k samples/s per half layer, 63.5-63.6 k with the
+// groups fused.  The weight gradients need their CU-time wherever they get it; the boundary tails are where they get it without displacing
+// anything.  Bit-identical (test_whole_stack_forward_launch_is_bit_identical), opt-in: m3l_set_enc_mega(3) / M3L_ENC_MEGA=3.
+struct MegaBwdLayer {
+    const bf16* dxt;                // feed-forward half: dx_t of this layer, saved x1, gamma2, u, W2^T, W1^T -> du, dx1_t, partial rows
+    const float *x1, *ln2_w;
+    const bf16 *u, *w2T, *w1T;
+    bf16 *du, *dx1t;
+    float *cs_part, *ln2_part;
+    const float *x, *ln1_w;         // attention half: the layer's input, gamma1, saved qkv / o / lse, Wo^T, Wqkv^T -> dqkv, dx, dx_t below
+    const bf16 *qkv, *o;
+    const float* lse;
+    const bf16 *woT, *wqkvT;
+    bf16* dqkv;
+    float* dx_out;
+    bf16* dxt_out;
+    float* ln1_part;
+};
+struct MegaBwdPack {
+    MegaBwdLayer L[M3L_MEGA_BWD_MAX_LAYERS];
+    int count;
+};
+
+template <int KT>
+__global__ __launch_bounds__(AB_THREADS) void enc_bwd_mega_kernel(float* __restrict__ dx, MegaBwdPack P, float eps, int n, int mlp) {
+    for (int step = 0; step < 2 * P.count; ++step) {
+        const MegaBwdLayer& L = P.L[step >> 1];
+        if ((step & 1) == 0)
+            mlp_block_bwd_body<KT>(L.dxt, dx, L.x1, L.ln2_w, L.u, L.w2T, L.w1T, eps, n, mlp, L.du, L.dx1t, L.cs_part, L.ln2_part);
+        else
+            attn_block_bwd_body<KT>(L.dx1t, dx, L.x, L.ln1_w, L.qkv, L.o, L.lse, L.woT, L.wqkvT, eps, n, L.dqkv, L.dx_out, L.dxt_out, L.ln1_part);
+        __syncthreads();
+    }
+}
+
+template <int KT> constexpr int mega_bwd_lds(int mlp) {
+    const int a = AbBwdLayout<KT>::TOTAL, b = MbLayout<KT>::TOTAL + 3 * mlp * (int)sizeof(float);
+    return a > b ? a : b;
+}
+
 }  // namespace
 
 static int g_enc_mega = -1;          // -1 = environment not read yet
 int m3l_enc_mega_enabled(void) {
-    if (g_enc_mega < 0) g_enc_mega = getenv("M3L_ENC_MEGA") ? atoi(getenv("M3L_ENC_MEGA")) : 1;      // bit 1: forward
+    if (g_enc_mega < 0) g_enc_mega = getenv("M3L_ENC_MEGA") ? atoi(getenv("M3L_ENC_MEGA")) : 1;      // bit 1: forward, bit 2: backward groups (opt-in: measured slower)
     return g_enc_mega;
 }
-// 1 (default) = one launch for the whole forward of a short-sequence stack, 0 = one launch per half layer; returns the previous setting
+// bit 1 = one launch for the whole forward of a short-sequence stack (default), bit 2 = one launch per weight-gradient group of layers
+// in its backward (opt-in), 0 = one launch per half layer; returns the previous setting
 extern "C" int m3l_set_enc_mega(int mode) {
     const int old = m3l_enc_mega_enabled();
     g_enc_mega = mode > 0 ? mode : 0;
@@ -108,3 +154,28 @@ int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* 
     return 0;
 }
 
+// Backward of `count` consecutive layers (top first).  layers[i] = the 21 pointers of MegaBwdLayer in declaration order; dx [B, n, D] fp32
+// is the running residual gradient (read and updated in place by every body).
+int m3l_enc_bwd_mega(int D, int mlp, int B, int n, float* dx, const void* const* layers, int count, float eps, hipStream_t st) {
+    static int inited_mlp = 0;
+    M3L_CHECK(D == 128 || D == 192, "enc_bwd_mega: D=%d unsupported", D);
+    M3L_CHECK(count >= 1 && count <= M3L_MEGA_BWD_MAX_LAYERS, "enc_bwd_mega: %d layers (max %d)", count, M3L_MEGA_BWD_MAX_LAYERS);
+    const int lds = D == 128 ? mega_bwd_lds<2>(mlp) : mega_bwd_lds<3>(mlp);
+    M3L_CHECK(lds <= 160 * 1024, "enc_bwd_mega: mlp=%d needs %d bytes of LDS", mlp, lds);
+    if (inited_mlp != mlp) {
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<2>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<3>(mlp)));
+        inited_mlp = mlp;
+    }
+    static_assert(sizeof(MegaBwdLayer) == 21 * sizeof(void*), "MegaBwdLayer is 21 pointers");
+    MegaBwdPack P;
+    memcpy(P.L, layers, (size_t)count * sizeof(MegaBwdLayer));
+    P.count = count;
+    ProfScope prof("enc_bwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st);
+    if (D == 128)
+        enc_bwd_mega_kernel<2><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
+    else
+        enc_bwd_mega_kernel<3><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}

@@ -157,8 +157,10 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
                        float* ln_part, hipStream_t st);
 // whole-stack launches for short sequences (enc_mega.hip): the bodies of the block kernels above, layer after layer in one launch
 #define M3L_MEGA_MAX_LAYERS 16
-int m3l_enc_mega_enabled(void);      // bit 1: forward (env M3L_ENC_MEGA, default 1)
+#define M3L_MEGA_BWD_MAX_LAYERS 4        // = the largest weight-gradient group (TfWs::wg_batch)
+int m3l_enc_mega_enabled(void);      // bit 1: forward, bit 2: backward groups (env M3L_ENC_MEGA, default 1)
 int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* const* layers, int count, float eps, hipStream_t st);
+int m3l_enc_bwd_mega(int D, int mlp, int B, int n, float* dx, const void* const* layers, int count, float eps, hipStream_t st);
 unsigned long long* m3l_attn_phase_buffer(void);
 // row-tiled fused half layers (t192.hip), bf16, model width D = 192 / 256 / 384: a workgroup owns 192 / 128 / 96 token rows, any M
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M);

@@ -804,7 +804,44 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         return 0;
     };
     const int csrows = m3l_gemm_nt_colsum_rows(M, mlp);
+    // short sequences whose both backward halves take a block kernel: one launch per weight-gradient group of layers (enc_mega.hip)
+    const bool mega_bwd = (m3l_enc_mega_enabled() & 2) && !fuse && c->project_out && m3l_mlp_block_bwd_supported(dt, D, mlp, n) &&
+                          !(m3l_mlp_t192_supported(dt, D, mlp, M) && m3l_mlp_t192_short()) && m3l_attn_block_bwd_enabled() &&
+                          m3l_attn_block_supported(dt, D, c->heads, n, c->project_out) && w.wg_batch <= M3L_MEGA_BWD_MAX_LAYERS;
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
+        if (mega_bwd && pend_sets.empty()) {
+            const int g_lo = std::max(layer_lo, l - w.wg_batch + 1), cnt = l - g_lo + 1;
+            const void* lay[M3L_MEGA_BWD_MAX_LAYERS][21];
+            for (int ll = l; ll >= g_lo; --ll) {
+                TfLayer& LL = w.L[ll];
+                const int cur = ll % NS, nxt = ll ? (ll - 1) % NS : 0;
+                const void* const* t = tensors + 11 * ll;
+                float* const* g = grads + 11 * ll;
+                if (ll && claim_set(nxt)) return 2;                 // the attention body of layer ll writes dx_t[nxt]
+                float* p2 = ln_slot(2 * ll + 1, g[5], g[6], g[4], B);
+                float* p1 = ln_slot(2 * ll, g[0], g[1], ll ? grads[11 * (ll - 1) + 10] : nullptr, B);
+                const void* v[21] = {w.dx_t[cur], LL.x1, t[5], LL.u, LL.w2T, LL.w1T, w.du[cur], w.dx1_t[cur], w.scratch2[cur], p2,
+                                     ll ? w.L[ll - 1].xout : x_in, t[0], LL.qkv, LL.o, LL.lse, LL.woT, LL.wqkvT, w.dqkv[cur],
+                                     (ll == 0 && dx_in) ? dx_in : w.dx, ll ? w.dx_t[nxt] : nullptr, p1};
+                memcpy(lay[l - ll], v, sizeof(v));
+            }
+            if (m3l_enc_bwd_mega(D, mlp, B, n, w.dx, &lay[0][0], cnt, LN_EPS, st)) return 1;
+            for (int ll = l; ll >= g_lo; --ll) {
+                TfLayer& LL = w.L[ll];
+                const int cur = ll % NS;
+                float* const* g = grads + 11 * ll;
+                const int hk = (drop_h() && fused_mlp_kind(c, B, n, fuse)) ? 2 : 0;
+                pend.push_back(TnProblem{w.dx_t[cur], hk ? LL.u : LL.h, D, mlp, D, mlp, g[9], mlp, D, mlp, 0, 0, hk});
+                pend.push_back(TnProblem{w.du[cur], LL.xn2, mlp, D, mlp, D, g[7], D, mlp, D, 0, 0});
+                pend.push_back(TnProblem{w.dqkv[cur], LL.xn1, 3 * HD, D, 3 * HD, D, g[2], D, 3 * HD, D, 0, 0});
+                pend.push_back(TnProblem{w.dx1_t[cur], LL.o, D, HD, D, HD, g[3], HD, D, HD, 0, 0});
+                pend_ex.push_back(TnExtra{w.scratch2[cur], g[8], B, mlp});
+                pend_sets.push_back(cur);
+            }
+            if (int rc = flush_wgrads()) return rc;
+            l = g_lo;
+            continue;
+        }
         TfLayer& L = w.L[l];
         const int cur = l % NS, nxt = l ? (l - 1) % NS : 0;
         const float* xl = l ? w.L[l - 1].xout : x_in;

@@ -151,10 +151,11 @@ def test_t192_row_tiled_kernels(D, heads, mlp, n, B):
         assert _relmax(y, y0) <= 5e-3 and _relmax(dx, dx0) <= 1e-2 and worst[1] <= 2e-2, on
 
 
-@pytest.mark.parametrize("D,heads,mlp,n,B,depth", [(192, 3, 768, 48, 5, 4), (128, 2, 256, 33, 3, 3), (192, 3, 384, 17, 2, 16)])
+@pytest.mark.parametrize("D,heads,mlp,n,B,depth", [(192, 3, 768, 48, 5, 4), (128, 2, 256, 33, 3, 3), (192, 3, 384, 17, 2, 16), (192, 3, 768, 48, 7, 6)])
 def test_whole_stack_forward_launch_is_bit_identical(D, heads, mlp, n, B, depth):
-    """enc_mega.hip: the forward of a short-sequence stack as ONE launch (the block kernels' bodies layer after layer) against one launch
-    per half layer (m3l_set_enc_mega): outputs, input gradient and every parameter gradient bit-identical."""
+    """enc_mega.hip: the forward of a short-sequence stack as ONE launch and its backward as one launch per weight-gradient group of layers
+    (the block kernels' bodies back to back; depth 6 and 3 leave a shorter last group) against one launch per half layer
+    (m3l_set_enc_mega bits 1 / 2): outputs, input gradient and every parameter gradient bit-identical."""
     torch.manual_seed(D + n)
     tf = Transformer(D, depth, heads, 64, mlp)
     tf.compute_dtype = "bf16"
@@ -163,14 +164,15 @@ def test_whole_stack_forward_launch_is_bit_identical(D, heads, mlp, n, B, depth)
     x = (torch.randn(B, n, D, generator=g) * 1.5).to(DEV)
     cot = torch.randn(B, n, D, generator=g).to(DEV)
     res = {}
-    for mega in (0, 1):
+    for mega in (0, 1, 2, 3):
         old = L.lib().m3l_set_enc_mega(mega)
         try:
             res[mega] = _run(tf, x, cot, 3)
         finally:
             L.lib().m3l_set_enc_mega(old)
     y0, dx0, g0 = res[0]
-    y1, dx1, g1 = res[1]
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
+    for mega in (1, 2, 3):
+        y1, dx1, g1 = res[mega]
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1), mega
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (mega, k)

@@ -85,7 +85,8 @@ def test_gemm_nt_epilogues(dev, code):
 
 
 @pytest.mark.parametrize("code", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(512, 128, 128), (1000, 192, 576), (333, 48, 192), (4096, 768, 192), (70, 8, 200)])
+@pytest.mark.parametrize("M,N,K", [(512, 128, 128), (1000, 192, 576), (333, 48, 192), (4096, 768, 192), (70, 8, 200), (9000, 576, 192),
+                                   (2500, 1536, 384), (8300, 192, 768), (300, 264, 136)])
 def test_gemm_tn(dev, code, M, N, K):
     torch.manual_seed(M + N)
     Y = torch.randn(M, N, device=dev).to(_t(code))

@@ -69,7 +69,10 @@ __global__ __launch_bounds__(AB_THREADS) void enc_fwd_mega_kernel(const float* _
     }
 }
 
-template <int KT> constexpr int mega_fwd_lds() { return AbLayout<KT>::TOTAL > MbLayout<KT>::TOTAL ? AbLayout<KT>::TOTAL : MbLayout<KT>::TOTAL; }
+template <int KT> constexpr int mega_fwd_lds(int mlp) {     // the feed-forward body keeps b1 [mlp] behind its fixed layout
+    const int a = AbLayout<KT>::TOTAL, b = MbLayout<KT>::TOTAL + mlp * (int)sizeof(float);
+    return a > b ? a : b;
+}
 
 // Backward of a GROUP of layers (the layers whose weight gradients go out as one grouped launch on the side stream) in one launch: per
 // layer the feed-forward backward body, then the attention backward body, top layer first.  Every tensor a body hands to the next one (the
@@ -133,11 +136,11 @@ extern "C" int m3l_set_enc_mega(int mode) {
 
 // x0 [B, n, D] fp32; layers[i] = the 20 pointers of MegaFwdLayer in declaration order
 int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* const* layers, int count, float eps, hipStream_t st) {
-    static int inited = 0;
-    if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<2>()));
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<3>()));
-        inited = 1;
+    static int inited_mlp = 0;
+    if (inited_mlp != mlp) {
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<2>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<3>(mlp)));
+        inited_mlp = mlp;
     }
     M3L_CHECK(D == 128 || D == 192, "enc_fwd_mega: D=%d unsupported", D);
     M3L_CHECK(count >= 1 && count <= M3L_MEGA_MAX_LAYERS, "enc_fwd_mega: %d layers (max %d)", count, M3L_MEGA_MAX_LAYERS);
@@ -147,9 +150,9 @@ int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* 
     P.count = count;
     ProfScope prof("enc_fwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st);
     if (D == 128)
-        enc_fwd_mega_kernel<2><<<B, AB_THREADS, mega_fwd_lds<2>(), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+        enc_fwd_mega_kernel<2><<<B, AB_THREADS, mega_fwd_lds<2>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
     else
-        enc_fwd_mega_kernel<3><<<B, AB_THREADS, mega_fwd_lds<3>(), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+        enc_fwd_mega_kernel<3><<<B, AB_THREADS, mega_fwd_lds<3>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
     M3L_LAUNCH_CHECK();
     return 0;
 }

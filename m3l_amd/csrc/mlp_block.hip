@@ -65,6 +65,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
     char* XN = smem;                                      // [48][XN_PITCH] bf16 xn2
     char* HC = smem + Ly::XN_BYTES;                       // [2][u | h][48][HC_PITCH]
     char* WR = HC + 4 * Ly::HC_BYTES;                     // NSTAGE x WBLK, later y f32 [48][Y_PITCH]
+    float* B1S = reinterpret_cast<float*>(WR + Ly::NSTAGE * Ly::WBLK);    // [mlp] fc1 bias (see the chunk loop)
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* gl_vp;
 
@@ -134,6 +135,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
             if (r < n) v = *reinterpret_cast<const uint4*>(xn2 + (row0 + r) * D + c * 8);
             *reinterpret_cast<uint4*>(XN + r * Ly::XN_PITCH + c * 16) = v;
         }
+        for (int id = tid; id < mlp; id += 64 * MB_CW) B1S[id] = b1[id];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0
@@ -160,10 +162,12 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
 #pragma unroll
     for (int j = 0; j < 3; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float bias_next = b1[16 * ct + li];                                  // b1 of chunk c is fetched during chunk c - 1 (a global load per
-    for (int c = 0; c < NC; ++c) {                                        // chunk with its latency exposed cost 2 000 cycles per chunk)
-        const float bias = bias_next;
-        if (c + 1 < NC) bias_next = b1[64 * (c + 1) + 16 * ct + li];
+    // The chunk loop issues NO vector-memory load: a wave's vmcnt counts its loads and stores together and they may complete out of
+    // order, so whenever a wave that has stores in flight needs a load's result the compiler must wait for vmcnt(0) — with b1 fetched
+    // from global memory once per chunk (even a chunk ahead) that was the HBM round trip of the chunk's u / h stores, 12 times per
+    // kernel.  b1 comes from LDS; the stores are never waited for inside the loop.
+    for (int c = 0; c < NC; ++c) {
+        const float bias = B1S[64 * c + 16 * ct + li];
         char* US = HC + (c & 1) * 2 * Ly::HC_BYTES;
         char* HS = US + Ly::HC_BYTES;
         __builtin_amdgcn_s_barrier();                                     // W1 chunk c landed (block 2c)
@@ -254,7 +258,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
 //     dxn2 = du W1                                    [n, D]     (kept in fp32, never leaves the CU)
 //     dx1  = dx + LN2-backward(dxn2; x1, gamma2)      in place, + compute-type copy, + [3 D] partials (dgamma2 | dbeta2 | colsum dx1)
 // Same ring / barrier structure as the forward with (W2^T, W1^T) in place of (W1, W2): block 2c = rows 64c.. of W2^T [mlp][D],
-// block 2c + 1 = columns 64c.. of W1^T [D][mlp].  u arrives one chunk ahead through registers.
+// block 2c + 1 = columns 64c.. of W1^T [D][mlp].  The DMA wave brings chunk c of u with block 2c.
 template <int KT>
 __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt, float* __restrict__ dx,
                                                                      const float* __restrict__ x1, const float* __restrict__ ln2_w,
@@ -293,6 +297,14 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
                     for (int kt = 0; kt < KT; ++kt)
                         __builtin_amdgcn_global_load_lds((gl_vp)(src + kt * 64), (lds_vp)(dst + kt * 8192 + rg * 1024), 16, 0, 0);
                 }
+                // ... and the chunk's u [48][64] as 128-byte rows into US[c & 1] (rows past n: the last row again, never used).  The compute
+                // waves store du every chunk: a load of theirs would make them wait for those stores' round trip (see the forward).
+                char* us = HC + (c & 1) * 2 * Ly::HC_BYTES;
+#pragma unroll
+                for (int pc = 0; pc < 6; ++pc) {
+                    const int r = min(8 * pc + srow, n - 1);
+                    __builtin_amdgcn_global_load_lds((gl_vp)(u + (row0 + r) * mlp + 64 * c + spc * 8), (lds_vp)(us + pc * 1024), 16, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int rg = 0; rg < 8; ++rg) {
@@ -309,10 +321,11 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
         if (NB > 2) issue(2);
         __builtin_amdgcn_s_barrier();                                     // B0
         for (int blk = 0; blk < NB; ++blk) {
+            // blocks blk + 1 and blk + 2 may remain in flight: one of the two is even and carries its chunk's 6 u pieces
             if (blk + 2 < NB) {
-                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-            } else if (blk + 1 < NB) {
+                if (NDMA == 16) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+            } else if (blk + 1 < NB) {                                    // blk + 1 = NB - 1 is odd: no u pieces
                 if (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
@@ -338,10 +351,6 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
         }
         for (int id = tid; id < 3 * mlp; id += 64 * MB_CW) CS[id] = 0.f;
     }
-    const int ur = tid >> 3, uc = tid & 7;                                // u chunk loader: thread -> (row, 16-byte piece), tid < 384
-    uint4 u_next = uint4{0u, 0u, 0u, 0u};
-    if (tid < 384 && ur < n) u_next = *reinterpret_cast<const uint4*>(u + (row0 + ur) * mlp + uc * 8);
-    if (tid < 384) *reinterpret_cast<uint4*>(HC + ur * Ly::HC_PITCH + uc * 16) = u_next;          // US[0]
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0
 
@@ -370,8 +379,7 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
     for (int c = 0; c < NC; ++c) {
         char* US = HC + (c & 1) * 2 * Ly::HC_BYTES;
         char* DS = US + Ly::HC_BYTES;
-        if (c + 1 < NC && tid < 384 && ur < n) u_next = *reinterpret_cast<const uint4*>(u + (row0 + ur) * mlp + 64 * (c + 1) + uc * 8);
-        __builtin_amdgcn_s_barrier();                                     // W2^T chunk c landed (block 2c); u chunk c visible
+        __builtin_amdgcn_s_barrier();                                     // W2^T chunk c and u chunk c landed (block 2c)
         if (rt < RT) {
             const char* Wb = WR + ((2 * c) % Ly::NSTAGE) * Ly::WBLK;
             const int wrow = 16 * ct + li;
@@ -390,7 +398,7 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = (16 * rt + 4 * g + r) * Ly::HC_PITCH + (16 * ct + li) * 2;
-                const float uv = (float)*reinterpret_cast<const bf16*>(US + off);
+                const float uv = (float)*reinterpret_cast<const bf16*>(US + (16 * rt + 4 * g + r) * 128 + (16 * ct + li) * 2);   // DMA image: 128-byte rows
                 const bf16 db_ = (bf16)(acc[r] * gelu_grad_fast(uv));
                 *reinterpret_cast<bf16*>(DS + off) = db_;
                 csum += (float)db_;
@@ -423,9 +431,6 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
 #pragma unroll
                 for (int j = 0; j < KT; ++j) yacc[j] = mma16(fa[ks], fw2[j][ks], yacc[j]);
         }
-        // u chunk c + 1 into the other buffer (last read two barriers ago)
-        if (c + 1 < NC && tid < 384) *reinterpret_cast<uint4*>(HC + ((c + 1) & 1) * 2 * Ly::HC_BYTES + ur * Ly::HC_PITCH + uc * 16) = u_next;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                                         // BE1: ring free, all column sums written
     float* Y = reinterpret_cast<float*>(WR);
@@ -531,11 +536,13 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* _
 
 #ifndef M3L_BLOCK_BODIES_ONLY
 
+static size_t mb_fwd_lds(int kt, int mlp);
 int m3l_mlp_block_supported(int dtype, int D, int mlp, int n) {
-    return m3l_attn_block_supported(dtype, D, D / 64, n, 1) && mlp % 64 == 0 && mlp >= 64;
+    return m3l_attn_block_supported(dtype, D, D / 64, n, 1) && mlp % 64 == 0 && mlp >= 64 && mb_fwd_lds(D / 64, mlp) <= 160 * 1024;
 }
 
-// LDS of the backward: the forward layout + [3][mlp] floats of column sums
+// LDS of the forward: the layout + [mlp] floats (b1); of the backward: the layout + [3][mlp] floats of column sums
+static size_t mb_fwd_lds(int kt, int mlp) { return (kt == 2 ? MbLayout<2>::TOTAL : MbLayout<3>::TOTAL) + (size_t)mlp * sizeof(float); }
 static size_t mb_bwd_lds(int kt, int mlp) { return (kt == 2 ? MbLayout<2>::TOTAL : MbLayout<3>::TOTAL) + (size_t)3 * mlp * sizeof(float); }
 
 int m3l_mlp_block_bwd_supported(int dtype, int D, int mlp, int n) {
@@ -565,16 +572,16 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
 
 int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* u, void* h, float* xout, hipStream_t st) {
-    static int inited = 0;
-    if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MbLayout<2>::TOTAL));
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, MbLayout<3>::TOTAL));
-        inited = 1;
+    static int inited_mlp = 0;
+    if (inited_mlp != mlp) {
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(3, mlp)));
+        inited_mlp = mlp;
     }
     M3L_CHECK(D == 128 || D == 192, "mlp_block: D=%d unsupported", D);
     ProfScope prof("mlp_block_fwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
 #define MB_LAUNCH(KT)                                                                                                                  \
-    mlp_block_fwd_kernel<KT><<<B, MB_THREADS, MbLayout<KT>::TOTAL, st>>>((const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, n, \
+    mlp_block_fwd_kernel<KT><<<B, MB_THREADS, mb_fwd_lds(KT, mlp), st>>>((const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, n, \
                                                                         mlp, (bf16*)u, (bf16*)h, xout)
     if (D == 128) MB_LAUNCH(2);
     else MB_LAUNCH(3);

@@ -67,6 +67,8 @@ template <int D, int TT, int CP> struct TileCfg {
 };
 // tile shape used for width D when the tile is not chosen per M (D = 192: <12, 1> / <3, 2>)
 template <int D> struct WideTile { static constexpr int TT = D == 256 ? 8 : 6; };
+typedef __attribute__((ext_vector_type(4))) unsigned int u4v_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u2v_t;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int PFD = 1;                       // fragment prefetch distance of the chunk bodies, in steps
 
@@ -156,15 +158,29 @@ __device__ __forceinline__ void dma_ring(int dw, int nc, char* ring, Issue issue
 }
 
 // this wave's 16 tokens of a bf16 activation [M][D] as the B fragments of all KS k steps: lane (i = token, g) <- k = 32 ks + 8 g ..
+// lrow = the token's row, or any valid row for a token past the end (ok = false: the value is dropped).  The loads are UNCONDITIONAL: a
+// load under a lane-dependent `if` gets a basic block of its own together with its wait, so KS guarded loads are KS dependent round
+// trips (tools/asm_roundtrips.py) — and these kernels run one workgroup per CU with every wave in the same phase: nothing hides them.
 template <int KS>
-__device__ __forceinline__ void load_tok_frags(const bf16* __restrict__ X, long trow, bool ok, int g, Frag<bf16> (&fb)[KS]) {
+__device__ __forceinline__ void load_tok_frags(const bf16* __restrict__ X, long lrow, bool ok, int g, Frag<bf16> (&fb)[KS]) {
     constexpr int D = 32 * KS;
+    uint4 v[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const uint4*>(X + trow * D + ks * 32 + 8 * g);
-        fb[ks].v = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int ks = 0; ks < KS; ++ks) v[ks] = *reinterpret_cast<const uint4*>(X + lrow * D + ks * 32 + 8 * g);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fb[ks].v = __builtin_bit_cast(bf16x8, ok ? v[ks] : uint4{0u, 0u, 0u, 0u});
+}
+// 16-byte / 8-byte store of a row piece through a buffer descriptor whose bound is the end of the matrix; a lane whose token lies past the
+// end (or that must not write) passes on = false and gets an offset past the bound: the hardware drops the write, no branch is needed
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+constexpr int ROW_OOB = 0x7fffffff;                          // row offset of a lane that must not write
+__device__ __forceinline__ void store_row16(__amdgpu_buffer_rsrc_t r, int rowoff, int byteoff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v_t, v), r, (int)((unsigned)rowoff + (unsigned)byteoff), 0, 0);
+}
+__device__ __forceinline__ void store_row8(__amdgpu_buffer_rsrc_t r, int rowoff, int byteoff, bf16x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v_t, v), r, (int)((unsigned)rowoff + (unsigned)byteoff), 0, 0);
 }
 
 // sum of the CP partial accumulators of a token tile into its parity-0 wave (fixed order cp = 0, 1, ..): two barriers when CP > 1.
@@ -194,7 +210,7 @@ __device__ __forceinline__ void reduce_to_parity0(char* RED, int tw, int cp, int
 // LDS: ring 4 x 24 KiB (later RED) | b1 [mlp] f32 | b2 [192] f32
 template <int D, int TT, int CP> struct MlpFwdLayout {
     static constexpr int RING = 0, B1 = TileCfg<D, TT, CP>::RING;
-    static size_t total(int mlp) { return (size_t)B1 + (size_t)mlp * 4 + D * 4; }
+    static size_t total(int mlp) { return (size_t)B1 + (size_t)mlp * 4 + 4 * D * 4; }     // b1 [mlp] | b2 | (PRO: bo | gamma2 | beta2) [D] each
 };
 
 // PRO = 1: the attention half's tail runs first, in the same launch (needs CP = 1 and heads * 64 == D):
@@ -245,15 +261,35 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     const int tw = wave % TT, cp = wave / TT;
     const long trow = row0 + 16 * tw + li;                    // this lane's token (column of every accumulator tile)
     const bool ok = trow < M;
+    const long lrow = ok ? trow : (long)M - 1;                // a valid row for the unconditional loads of a token past the end
+    const int xoff = ok ? (int)(trow * D * 4) : ROW_OOB;      // byte offset of the token's fp32 row for the bounded stores (past the bound: dropped)
     for (int id = tid; id < mlp; id += 64 * NCW) B1[id] = b1[id];                 // shared: the first ring barrier orders them
     for (int id = tid; id < D; id += 64 * NCW) B2[id] = b2[id];
+    float* PV = B2 + D;                                       // PRO: bo | ln_w | ln_b, read after the prologue's stage barriers
+    if (PRO) {
+        for (int id = tid; id < D; id += 64 * NCW) {
+            PV[id] = pro.bo[id];
+            PV[D + id] = pro.ln_w[id];
+            PV[2 * D + id] = pro.ln_b[id];
+        }
+    }
     Frag<bf16> xb[KS];
     if (!PRO) {
-        load_tok_frags(xn2, trow, ok, g, xb);
+        load_tok_frags(xn2, lrow, ok, g, xb);
     } else {
         Frag<bf16> ob[KS];
-        load_tok_frags(pro.o, trow, ok, g, ob);
+        load_tok_frags(pro.o, lrow, ok, g, ob);
+        // x1 = x + bo + o Wo^T: the accumulators START as x + bo (the lane's columns 32 c + 8 g + 4 t + r), all of the row requested now, in
+        // one batch that lands behind the first Wo stage — added after the products, under `if (ok)` next to the x1 store, these were 12
+        // load -> wait -> store steps in a row, each wait also draining the store before it (a wave's vmcnt covers loads and stores alike)
         f32x4 pa[KS][2];
+#pragma unroll
+        for (int c = 0; c < KS; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int col = 32 * c + 8 * g + 4 * t;
+                pa[c][t] = *reinterpret_cast<const f32x4*>(pro.x + lrow * D + col) + *reinterpret_cast<const f32x4*>(pro.bo + col);
+            }
 #pragma unroll
         for (int s0 = 0; s0 < PRO_STAGES; ++s0) {
             __builtin_amdgcn_s_barrier();                     // Wo stage landed
@@ -262,8 +298,6 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int c = 2 * s0 + bb;
-                pa[c][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                pa[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     pa[c][0] = mma16(frag_f1p(Ws + bb * Cf::BLK, 0, ks, li, g), ob[ks], pa[c][0]);
@@ -271,19 +305,16 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
                 }
             }
         }
-        // x1 = x + y + bo on the lane's columns 32 c + 8 g + 4 t + r; LayerNorm over the token (in-lane sums + the 4 lane groups)
+        // x1 leaves (for the residual add at the end and for the backward); LayerNorm over the token (in-lane sums + the 4 lane groups)
+        const __amdgpu_buffer_rsrc_t rx1 = rows_rsrc(pro.x1_out, (long)M * D * 4);
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < KS; ++c)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = 32 * c + 8 * g + 4 * t;
-                f32x4 v = pa[c][t] + *reinterpret_cast<const f32x4*>(pro.bo + col);
-                if (ok) {
-                    v += *reinterpret_cast<const f32x4*>(pro.x + trow * D + col);
-                    *reinterpret_cast<f32x4*>(pro.x1_out + trow * D + col) = v;
-                }
-                pa[c][t] = v;
+                const f32x4 v = pa[c][t];
+                store_row16(rx1, xoff, col * 4, v);
                 sum += (v[0] + v[1]) + (v[2] + v[3]);
             }
         const float mean = col4_sum(sum) * (1.0f / D);
@@ -301,7 +332,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = 32 * c + 8 * g + 4 * t;
-                const f32x4 r = pa[c][t] * rstd * *reinterpret_cast<const f32x4*>(pro.ln_w + col) + *reinterpret_cast<const f32x4*>(pro.ln_b + col);
+                const f32x4 r = pa[c][t] * rstd * *reinterpret_cast<const f32x4*>(PV + D + col) + *reinterpret_cast<const f32x4*>(PV + 2 * D + col);   // (LDS: a global load here would wait for the x1 stores)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[c].v[4 * t + e] = (bf16)r[e];
             }
@@ -383,12 +414,19 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     }
     // xout = x1 + y + b2: a lane holds 4 consecutive columns of its token per tile (parity 0 finishes the token tile)
     reduce_to_parity0<TT, CP, ND>(RING, tw, cp, lane, yacc);
-    if (ok && cp == 0 && (!(T192_ABL & 8) || yacc[0][0] == 1234.5f)) {
+    if (cp == 0 && (!(T192_ABL & 8) || yacc[0][0] == 1234.5f)) {          // wave-uniform
+        // the residual row in ONE batch of loads, then the stores (with the x1 pointer of the prologue the compiler cannot tell x1 from
+        // xout and kept load d behind store d - 1: twelve round trips at the end of the kernel)
+        f32x4 r1[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) r1[d] = *reinterpret_cast<const f32x4*>(x1 + lrow * D + 16 * d + 4 * g);
+        asm volatile("" ::: "memory");
+        const __amdgpu_buffer_rsrc_t rxo = rows_rsrc(xout, (long)M * D * 4);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int col = 16 * d + 4 * g;
-            const f32x4 v = yacc[d] + *reinterpret_cast<const f32x4*>(B2 + col) + *reinterpret_cast<const f32x4*>(x1 + trow * D + col);
-            *reinterpret_cast<f32x4*>(xout + trow * D + col) = v;
+            const f32x4 v = yacc[d] + *reinterpret_cast<const f32x4*>(B2 + col) + r1[d];
+            store_row16(rxo, xoff, col * 4, v);
         }
     }
 }
@@ -416,62 +454,96 @@ template <int D, int TT, int CP> struct MlpBwdLayout {
 template <int ND>
 __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float* __restrict__ x, const float* G,
                                             const float* __restrict__ dres, float* __restrict__ dx_out, bf16* __restrict__ dxt_out, float eps,
-                                            long trow, bool active, char* lp_base, int wave, int lane) {
+                                            long trow, long lrow, long M, bool active, char* lp_base, int wave, int lane) {
     constexpr int T_D = 16 * ND;
     const int g = lane >> 4, li = lane & 15;
-    f32x4 xh[ND];
+    // Every load below is unconditional (lrow = a valid row for a token past the end; its values are dropped) and every store goes through
+    // a bounded descriptor (a lane that must not write passes an offset past the bound): straight-line code, so that a row's loads go out
+    // as batches.  Guarded by `if (active)` they were one basic block — one wait — each: 12 round trips for x and, in the last loop,
+    // 12 times load dres -> wait -> store, where every wait also drains the store in front of it (vmcnt counts loads and stores alike).
+    // The row of x is read three times (mean; centred sums; output) instead of being held: with the 48 accumulator registers live, 48
+    // more for x put the kernel past its 128-VGPR cap, and a spill reload is one more vector-memory load whose wait drains the stores.
+    // The second and third reads come from L2.
+    constexpr int BT = ND % 6 == 0 ? 6 : 4;                   // row pieces requested per batch
+    static_assert(ND % BT == 0, "ND is a multiple of the batch");
+    const bool use = active && !(T192_ABL & 32);
+    const float* xr = x + lrow * T_D + 4 * g;                 // (not const-qualified as a variable: laundered between the passes)
     float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        xh[d] = (active && !(T192_ABL & 32)) ? *reinterpret_cast<const f32x4*>(x + trow * T_D + 16 * d + 4 * g) : f32x4{0.f, 0.f, 0.f, (float)d};
-        s += (xh[d][0] + xh[d][1]) + (xh[d][2] + xh[d][3]);
+    for (int d0 = 0; d0 < ND; d0 += BT) {
+        f32x4 v[BT];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            if (!use) v[j] = f32x4{0.f, 0.f, 0.f, (float)(d0 + j)};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
     }
     const float mean = col4_sum(s) * (1.0f / T_D);
-    float q = 0.f;
+    asm volatile("" : "+v"(xr));
+    float q = 0.f, s1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        xh[d] = xh[d] - mean;
-        q += (xh[d][0] * xh[d][0] + xh[d][1] * xh[d][1]) + (xh[d][2] * xh[d][2] + xh[d][3] * xh[d][3]);
+    for (int d0 = 0; d0 < ND; d0 += BT) {
+        f32x4 v[BT];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int d = d0 + j;
+            if (!use) v[j] = f32x4{0.f, 0.f, 0.f, (float)d};
+            const f32x4 xc = v[j] - mean;
+            q += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+            const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + 16 * d + 4 * g);
+            s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
+            const f32x4 t = gd * xc;
+            t2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
     }
     const float rstd = rsqrtf(col4_sum(q) * (1.0f / T_D) + eps);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        xh[d] = xh[d] * rstd;
-        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + 16 * d + 4 * g);
-        s1 += (gd[0] + gd[1]) + (gd[2] + gd[3]);
-        const f32x4 t = gd * xh[d];
-        s2 += (t[0] + t[1]) + (t[2] + t[3]);
-    }
     s1 = col4_sum(s1) * (1.0f / T_D);
-    s2 = col4_sum(s2) * (1.0f / T_D);
+    const float s2 = col4_sum(t2) * rstd * (1.0f / T_D);     // mean of gd * xhat, xhat = (x - mean) * rstd
+    asm volatile("" : "+v"(xr));                              // (an opaque copy: the re-reads must not be merged with the first pass's loads)
     __builtin_amdgcn_s_barrier();                             // T1: every wave is done with the region LP aliases
     float* LP = reinterpret_cast<float*>(lp_base) + wave * 3 * T_D;
+    const int roff32 = use ? (int)(trow * T_D * 4) : ROW_OOB, roff16 = use ? (int)(trow * T_D * 2) : ROW_OOB;
+    const __amdgpu_buffer_rsrc_t rdx = rows_rsrc(dx_out, M * T_D * 4), rdt = rows_rsrc(dxt_out, M * T_D * 2);
+    constexpr int BO = 4;                                     // (x, dres) pairs per batch of the output pass
+    static_assert(ND % BO == 0, "ND is a multiple of the batch");
+    const float* dr_ = dres + lrow * T_D + 4 * g;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const int col = 16 * d + 4 * g;
-        const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
-        f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (active && (T192_ABL & 32)) rr = (gd - s1 - xh[d] * s2) * rstd;
-        if (active && !(T192_ABL & 32)) {
-            rr = (gd - s1 - xh[d] * s2) * rstd + *reinterpret_cast<const f32x4*>(dres + trow * T_D + col);
-            *reinterpret_cast<f32x4*>(dx_out + trow * T_D + col) = rr;
-            if (dxt_out) {
-                bf16x4 pk;
-                pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
-                *reinterpret_cast<bf16x4*>(dxt_out + trow * T_D + col) = pk;
+    for (int d0 = 0; d0 < ND; d0 += BO) {
+        f32x4 v[BO], dr[BO];
+#pragma unroll
+        for (int j = 0; j < BO; ++j) {
+            v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
+            dr[j] = *reinterpret_cast<const f32x4*>(dr_ + 16 * (d0 + j));
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < BO; ++j) {
+            const int d = d0 + j, col = 16 * d + 4 * g;
+            if (!use) v[j] = f32x4{0.f, 0.f, 0.f, (float)d};
+            const f32x4 xh = (v[j] - mean) * rstd;
+            const f32x4 gd = yacc[d] * *reinterpret_cast<const f32x4*>(G + col);
+            f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (active) rr = (gd - s1 - xh * s2) * rstd;
+            if (use) rr += dr[j];
+            store_row16(rdx, roff32, col * 4, rr);
+            bf16x4 pk;
+            pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
+            store_row8(rdt, roff16, col * 2, pk);
+            f32x4 pg = yacc[d] * xh, pb = yacc[d], pc = rr;
+            if (!active) { pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pg[e] = row16_sum_t(pg[e]); pb[e] = row16_sum_t(pb[e]); pc[e] = row16_sum_t(pc[e]);
             }
-        }
-        f32x4 pg = yacc[d] * xh[d], pb = yacc[d], pc = rr;
-        if (!active) { pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pg[e] = row16_sum_t(pg[e]); pb[e] = row16_sum_t(pb[e]); pc[e] = row16_sum_t(pc[e]);
-        }
-        if (li == 0) {
-            *reinterpret_cast<f32x4*>(LP + col) = pg;
-            *reinterpret_cast<f32x4*>(LP + T_D + col) = pb;
-            *reinterpret_cast<f32x4*>(LP + 2 * T_D + col) = pc;
+            if (li == 0) {
+                *reinterpret_cast<f32x4*>(LP + col) = pg;
+                *reinterpret_cast<f32x4*>(LP + T_D + col) = pb;
+                *reinterpret_cast<f32x4*>(LP + 2 * T_D + col) = pc;
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -510,14 +582,17 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     const long trow = row0 + 16 * tw + li;
     const bool ok = trow < M;
     Frag<bf16> db[KS];
-    load_tok_frags(dxt, trow, ok, g, db);
+    load_tok_frags(dxt, ok ? trow : (long)M - 1, ok, g, db);
     for (int id = tid; id < D; id += 64 * NCW) G[id] = ln2_w[id];
     float* CSw = Lay::CS_LDS ? CS + tw * mlp : cs_part + ((long)blockIdx.x * TT + tw) * mlp;
 
     f32x4 yacc[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 un = uint4{0u, 0u, 0u, 0u};                          // u of the lane's 8 hidden units of its next chunk (rows past M: 0)
+    // u of the lane's 8 hidden units of its next chunk (rows past M: 0).  (Staged by the DMA waves through an LDS ring of its own instead —
+    // so that this wave, which stores du every chunk, has no load to wait for and no vmcnt(0) per chunk: built and measured in round 3,
+    // 103 -> 108 us; the u pieces queue behind the weight pieces in the DMA waves.  Not kept.)
+    uint4 un = uint4{0u, 0u, 0u, 0u};
     if (ok && cp < NC) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * cp + 8 * g);
 
     for (int st = 0; st < NS; ++st) {
@@ -581,7 +656,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     }
     reduce_to_parity0<TT, CP, ND>(RING, tw, cp, lane, yacc); // (two barriers when CP > 1)
     // ---- LN2 backward on the registers (parity-0 waves; the others only keep the barrier count): T1, T2 inside
-    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok && cp == 0, RING, wave, lane);
+    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok && cp == 0, RING, wave, lane);
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * D; id += 64 * NCW) {
@@ -671,7 +746,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS), (TileCfg<D, TT, 1>::M
             yacc[d] = mma16(fa[1], b1, yacc[d]);
         }
     }
-    ln_bwd_rows(yacc, x, G, dres, dx_out, dxt_out, eps, trow, ok, RING, wave, lane);      // barriers T1, T2
+    ln_bwd_rows(yacc, x, G, dres, dx_out, dxt_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);      // barriers T1, T2
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * D; id += 64 * NCW) {
@@ -925,7 +1000,7 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_bwd_ke
     const long trow = row0 + tok;
 
     Frag<bf16> xb[KS];
-    load_tok_frags(dx1t, trow, ok, g, xb);
+    load_tok_frags(dx1t, ok ? trow : row0 + n - 1, ok, g, xb);
     for (int h = 0; h < H; ++h) {
         Frag<bf16> fq[2], fdo[2];
         float dpart = 0.f;

@@ -13,7 +13,7 @@ for ln in lines:
     if m:
         kern = m.group(1); cur = None; continue
     if kern is None: continue
-    m = re.match(r"^(\.LBB\d+_\d+):(.*)", ln)
+    m = re.match(r"^(\.LBB\d+_\d+|; %bb\.\d+):(.*)", ln)
     if m:
         cur = [kern, m.group(1), "Loop" in m.group(2), []]; blocks.append(cur); continue
     if "s_endpgm" in ln: kern = None; cur = None; continue

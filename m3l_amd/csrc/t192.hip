@@ -824,13 +824,19 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_ke
     // ---- LN1 on the lane's D / 4 columns 32 ks + 8 g + j (the B-fragment layout): token sums = registers + the 4 lane groups
     Frag<bf16> xb[KS];
     {
+        // the row in one batch of unconditional loads (a token past n reads the sample's last row and drops it: see load_tok_frags)
+        const float* xrow = x + (ok ? trow : row0 + n - 1) * D + 8 * g;
         f32x4 v[KS][2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) v[ks][t] = *reinterpret_cast<const f32x4*>(xrow + 32 * ks + 4 * t);
         float sum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                v[ks][t] = ok ? *reinterpret_cast<const f32x4*>(x + trow * D + 32 * ks + 8 * g + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!ok) v[ks][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sum += (v[ks][t][0] + v[ks][t][1]) + (v[ks][t][2] + v[ks][t][3]);
             }
         const float mean = col4_sum(sum) * (1.0f / D);
@@ -852,7 +858,11 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_ke
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[ks].v[4 * t + e] = ok ? (bf16)r[e] : (bf16)0.f;
             }
-            if (ok) *reinterpret_cast<bf16x8*>(xn1_out + trow * D + 32 * ks + 8 * g) = xb[ks].v;
+        }
+        // (the stores after ALL the gamma / beta loads: a load behind a store waits for the store's round trip as well)
+        if (ok) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(xn1_out + trow * D + 32 * ks + 8 * g) = xb[ks].v;
         }
     }
     for (int h = 0; h < H; ++h) {

@@ -21,7 +21,7 @@ for line in open(sys.argv[1]):
                 trips += 1
                 at_trip = issued
             done = target
-    elif t.startswith("s_endpgm"):
+    elif t.startswith(".Lfunc_end"):            # (not s_endpgm: a kernel whose DMA waves return early has several)
         out.append((name, issued, trips)); name = None
 for n, l, t in sorted(out, key=lambda r: -r[2]):
     if l:

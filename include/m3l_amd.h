@@ -61,9 +61,10 @@ int m3l_set_rowln(int enable);
  * the attention backward block; env M3L_ATTN_BLOCK sets the initial mode.  Returns the
  * previous mode.  The fused kernels read and write exactly the activations of the unfused ones. */
 int m3l_set_attn_block(int mode);
-/* Short-sequence stacks whose every half layer takes a block kernel: 1 (default) = the whole forward of the stack in ONE launch (the same
- * kernel bodies, layer after layer inside one workgroup per sample), 0 = one launch per half layer; env M3L_ENC_MEGA.  Returns the previous
- * setting.  Bit-identical results either way. */
+/* Short-sequence stacks whose every half layer takes a block kernel, a bit mask: 1 (default) = the whole forward of the stack in ONE launch
+ * (the same kernel bodies, layer after layer inside one workgroup per sample); 2 = also its backward as one launch per weight-gradient
+ * group of layers (opt-in: measured slower beside the side stream's weight gradients); 0 = one launch per half layer; env M3L_ENC_MEGA.
+ * Returns the previous setting.  Bit-identical results either way. */
 int m3l_set_enc_mega(int mode);
 /* Profiling hook of the forward attention block (tools/attn_phase_probe.py): dev_buf = device buffer of >= 8 * B uint64 that every later
  * launch fills, per sample, with the shader-clock stamps [start, LN1 done, QKV done, attention done, out-proj done, end]; NULL (the

@@ -6,12 +6,12 @@ R=$(cd $(dirname $0)/.. && pwd)
 O=$R/build_abl; mkdir -p $O/obj
 cd $R/m3l_amd/csrc
 for f in *.hip; do
-  [ $O/obj/${f%.hip}.o -nt $f ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f -o $O/obj/${f%.hip}.o &
+  [ $O/obj/${f%.hip}.o -nt $f ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c $f -o $O/obj/${f%.hip}.o &
 done
 wait
 F=${2:-t192}; MAC=${3:-T192_ABL}          # file and macro to vary (e.g. mlp_block MB_ABL)
 for b in ${1:-0 1 2 4 8 16}; do
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -D$MAC=$b -c $F.hip -o $O/obj/${F}_v$b.o && \
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -D$MAC=$b -c $F.hip -o $O/obj/${F}_v$b.o && \
     hipcc --offload-arch=gfx950 -fPIC -shared -o $O/lib${F}_$b.so $O/obj/${F}_v$b.o $(ls $O/obj/*.o | grep -v "_v[0-9]*.o" | grep -v "/$F.o") ) &
 done
 wait

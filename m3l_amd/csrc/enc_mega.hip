@@ -53,6 +53,8 @@ struct MegaFwdPack {
 template <int KT>
 __global__ __launch_bounds__(AB_THREADS) void enc_fwd_mega_kernel(const float* __restrict__ x0, MegaFwdPack P, float eps, int n, int mlp,
                                                                     unsigned long long* __restrict__ phase_ts) {
+    // (Odd workgroups started 8 - 40 K cycles late, so that the phases of neighbouring CUs interleave instead of running chip-wide in
+    // lockstep: 508 - 510 us with every delay, as without — the bodies are chains of dependent steps per sample, not bandwidth-bound phases.)
     // one body per loop iteration (even steps: attention half, odd steps: feed-forward half): with both bodies inlined one after the
     // other in the loop body the register allocator spills 74-118 VGPRs; as two branches of one loop their live ranges stay apart
     const float* x = x0;

@@ -278,12 +278,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const fl
     for (int k = 0; k < 8; ++k) a8[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     int i = 0;
     for (; i + 8 <= S; i += 8) {
+        // requested together, then added: written as `a8[k] += load` the compiler emitted load -> s_waitcnt vmcnt(0) -> add eight times in a
+        // row (tools/asm_roundtrips.py: 23 dependent round trips per thread for S = 23), i.e. this kernel WAS the chain its comment describes
+        f32x4 t8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a8[k] += *reinterpret_cast<const f32x4*>(P + (long)(i + k) * stride);
+        for (int k = 0; k < 8; ++k) t8[k] = *reinterpret_cast<const f32x4*>(P + (long)(i + k) * stride);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += t8[k];
     }
+    // the tail in one batch as well: a slab index past the end re-reads the last slab and adds nothing (each guarded load was a basic
+    // block with its own wait: up to seven dependent round trips for S = 23)
+    {
+        f32x4 t8[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (i + k < S) a8[k] += *reinterpret_cast<const f32x4*>(P + (long)(i + k) * stride);
+        for (int k = 0; k < 8; ++k) t8[k] = *reinterpret_cast<const f32x4*>(P + (long)min(i + k, S - 1) * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i + k < S) a8[k] += t8[k];
+    }
     f32x4 s0 = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     const int lane = f & 63, wt = f >> 6, t = wt % NT, w = wt / NT, x = t / NB, y = t % NB;
     const int ia = a0 + (w >> 1) * 64 + x * 16 + 4 * (lane >> 4);

@@ -272,6 +272,13 @@ int m3l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * to m3l_adam_step) */
 int m3l_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* torch.optim.AdamW semantics (VTMAE.initialize_training, pretrain_models.py:675: decoupled weight decay) with an optional fused
+ * torch.nn.utils.clip_grad_norm_(params, max_grad_norm) (pretrain_models.py:710) over the same flat gradient buffer: max_grad_norm > 0 ->
+ * norm_ws (>= 1026 floats, device) receives partial sums, then norm_ws[1024] = the clip coefficient min(1, max / (||grad_scale g|| + 1e-6))
+ * and norm_ws[1025] = the norm; the coefficient is applied inside the update, and with scale_grads != 0 the scaled gradient is also left in
+ * `grads` (what clip_grad_norm_ leaves behind).  max_grad_norm <= 0: no clipping, norm_ws may be NULL.  Three launches, fixed summation order. */
+int m3l_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, float max_grad_norm, float* norm_ws, int scale_grads, void* stream);
 /* graph-capturable form: the step counter lives on the device (int, incremented by the call) together with the two bias
  * corrections (float[2] scratch), so a captured launch stays correct on every replay (torch's Adam(capturable=True)) */
 int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

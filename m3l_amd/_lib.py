@@ -101,6 +101,7 @@ _SIGS = {
     "m3l_vt_load": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "m3l_vt_load2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_p, c_p, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_p, c_p]),
     "m3l_adam_step_dev": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_p, c_p, c_p]),
+    "m3l_adamw_step": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, C.c_float, C.c_float, c_p, c_i, c_p]),
     "m3l_adam_step": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, c_p]),
     "m3l_adam_step_scaled": (c_i, [c_p, c_p, c_p, c_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, C.c_float, c_p]),
     "m3l_prof_begin": (None, [C.c_char_p, c_i]),

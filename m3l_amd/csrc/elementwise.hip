@@ -535,21 +535,29 @@ __global__ __launch_bounds__(256) void tokens_assemble_bwd_kernel(const float* _
 
 // Adam over ONE flat parameter / gradient / moment buffer (reference optimizer: torch.optim.Adam(mae.parameters(), lr=1e-4),
 // models/ppo_mae.py:182-183): same update rule and operation order as torch's, one launch for all 7.3 M parameters.
-__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// DEC = 1: torch.optim.AdamW (the optimizer of VTMAE.initialize_training, pretrain_models.py:675): decoupled weight decay, p *= 1 - lr wd
+// before the Adam update, the gradient itself unchanged.  clip_dev (may be null): a device-side factor on the gradient — the
+// clip_grad_norm_ coefficient of pretrain_models.py:710, computed by gradnorm_* below — applied inside the update; with scale_g the
+// clipped gradient is also written back, as clip_grad_norm_ leaves it.
+template <int DEC>
+__global__ void adam_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                 const float* __restrict__ bc_dev, float gscale) {
+                                 const float* __restrict__ bc_dev, float gscale, const float* __restrict__ clip_dev, int scale_g) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     if (bc_dev) {            // graph-capturable form: bias corrections of the device-side step counter
         bc1 = bc_dev[0];
         bc2_sqrt = bc_dev[1];
     }
+    if (clip_dev) gscale *= clip_dev[0];
     if (i + 4 <= n) {
         f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
         f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gr = gg[j] * gscale + wd * pp[j];                // gscale: 1 / world of a SUM all-reduce (1.0f is exact)
+            gg[j] = gg[j] * gscale;                                     // gscale: 1 / world of a SUM all-reduce (1.0f is exact)
+            if (DEC) pp[j] = pp[j] * wd;                                // DEC: wd carries the factor 1 - lr * weight_decay
+            const float gr = DEC ? gg[j] : gg[j] + wd * pp[j];
             mm[j] = mm[j] + (gr - mm[j]) * (1.0f - b1);                 // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
             vv[j] = vv[j] * b2 + (1.0f - b2) * gr * gr;
             const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
@@ -558,13 +566,48 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
         *reinterpret_cast<f32x4*>(p + i) = pp;
         *reinterpret_cast<f32x4*>(m + i) = mm;
         *reinterpret_cast<f32x4*>(v + i) = vv;
+        if (scale_g) *reinterpret_cast<f32x4*>(g + i) = gg;
     } else {
         for (long k = i; k < n; ++k) {
-            const float gr = g[k] * gscale + wd * p[k];
+            const float gs = g[k] * gscale;
+            if (DEC) p[k] = p[k] * wd;
+            const float gr = DEC ? gs : gs + wd * p[k];
             m[k] = m[k] + (gr - m[k]) * (1.0f - b1);
             v[k] = v[k] * b2 + (1.0f - b2) * gr * gr;
             p[k] = p[k] - (lr / bc1) * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
+            if (scale_g) g[k] = gs;
         }
+    }
+}
+
+// torch.nn.utils.clip_grad_norm_(params, max_norm) over the flat gradient buffer (pretrain_models.py:710): out[0] = the clip coefficient
+// min(1, max_norm / (||gscale g||_2 + 1e-6)), out[1] = the norm.  Two launches, fixed summation order (bit-reproducible).
+__global__ __launch_bounds__(256) void gradnorm_part_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+            a0 += v[0] * v[0]; a1 += v[1] * v[1]; a2 += v[2] * v[2]; a3 += v[3] * v[3];
+        } else {
+            for (long k = i; k < n; ++k) a0 += g[k] * g[k];
+        }
+    }
+    const float w = wave_sum((a0 + a1) + (a2 + a3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void gradnorm_final_kernel(const float* __restrict__ part, int G, float gscale, float max_norm, float* __restrict__ out) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < G; i += 64) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(a) * fabsf(gscale);
+        const float c = max_norm / (norm + 1e-6f);
+        out[0] = c < 1.0f ? c : 1.0f;
+        out[1] = norm;
     }
 }
 
@@ -1367,7 +1410,31 @@ int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr
     M3L_CHECK(n > 0 && step >= 1, "adam: n=%ld step=%d", n, step);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
-    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, nullptr, gscale);
+    adam_flat_kernel<0><<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, const_cast<float*>(g), m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, nullptr, gscale, nullptr, 0);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+// AdamW (decoupled weight decay) with an optional fused clip_grad_norm_: max_norm > 0 -> norm_ws (>= 1026 floats) receives the partial
+// sums, then [1024] = the clip coefficient and [1025] = the gradient norm; scale_grads: also leave the clipped gradient in g
+int m3l_adamw_flat(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
+                   float max_norm, float* norm_ws, int scale_grads, hipStream_t st) {
+    M3L_CHECK(n > 0 && step >= 1, "adamw: n=%ld step=%d", n, step);
+    M3L_CHECK(max_norm <= 0.f || norm_ws, "adamw: clipping needs the norm workspace");
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
+    const float* clip = nullptr;
+    if (max_norm > 0.f) {
+        const int G = (int)std::min<long>(1024, cdiv(cdiv(n, 4), 256));
+        gradnorm_part_kernel<<<G, 256, 0, st>>>(g, n, norm_ws);
+        M3L_LAUNCH_CHECK();
+        gradnorm_final_kernel<<<1, 64, 0, st>>>(norm_ws, G, gscale, max_norm, norm_ws + 1024);
+        M3L_LAUNCH_CHECK();
+        clip = norm_ws + 1024;
+    }
+    const float decay = (float)(1.0 - (double)lr * (double)wd);      // as torch: param.mul_(1 - lr * weight_decay), the factor formed in double
+    adam_flat_kernel<1><<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, decay, bc1, bc2_sqrt, nullptr, gscale, clip,
+                                                              scale_grads && (clip || gscale != 1.0f));
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1377,7 +1444,7 @@ int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, floa
     M3L_CHECK(n > 0 && step_dev && bc_dev, "adam (device step): n=%ld", n);
     adam_bias_kernel<<<1, 1, 0, st>>>(step_dev, b1, b2, bc_dev);
     M3L_LAUNCH_CHECK();
-    adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, 1.0f, 1.0f, bc_dev, 1.0f);
+    adam_flat_kernel<0><<<cdiv(cdiv(n, 4), 256), 256, 0, st>>>(p, const_cast<float*>(g), m, v, n, lr, b1, b2, eps, wd, 1.0f, 1.0f, bc_dev, 1.0f, nullptr, 0);
     M3L_LAUNCH_CHECK();
     return 0;
 }

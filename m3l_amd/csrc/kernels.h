@@ -236,6 +236,8 @@ int k_tokens_assemble_bwd(const float* dtok, int B, int D, int n_img, int n_tac,
                             float* dmod, int accumulate, hipStream_t st);
 int m3l_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
                   float gscale, hipStream_t st);
+int m3l_adamw_flat(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
+                   float max_norm, float* norm_ws, int scale_grads, hipStream_t st);
 int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
                       int* step_dev, float* bc_dev, hipStream_t st);
 int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,

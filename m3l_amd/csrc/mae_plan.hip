@@ -1539,6 +1539,12 @@ int m3l_adam_step_scaled(float* params, const float* grads, float* exp_avg, floa
     return m3l_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
 }
 
+int m3l_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, float max_grad_norm, float* norm_ws, int scale_grads, void* stream) {
+    return m3l_adamw_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_grad_norm, norm_ws,
+                          scale_grads, (hipStream_t)stream);
+}
+
 int m3l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int* step_dev, float* bias_corr_dev, void* stream) {
     return m3l_adam_flat_dev(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, bias_corr_dev,

@@ -355,3 +355,30 @@ class FlatAdam:
             self._step_dev.fill_(self.step_count)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class FlatAdamW(FlatAdam):
+    """torch.optim.AdamW(params, lr, betas, eps, weight_decay=1e-2) — the optimizer of VTMAE.initialize_training
+    (pretrain_models.py:675) — with the `clip_grad_norm_(parameters, max_grad_norm)` of VTMAE.train_iterations
+    (pretrain_models.py:710) fused in: one reduction over the flat gradient buffer + one update launch (m3l_adamw_step) instead of
+    torch's per-tensor norm / multiply / AdamW kernels.  max_grad_norm=None: no clipping.  After step(), `last_grad_norm` is a device
+    scalar holding the gradient norm clip_grad_norm_ would have returned; the clipped gradients are left in `.grad`, as it leaves them."""
+
+    def __init__(self, sync: GradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+        super().__init__(sync, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=False)
+        self.max_grad_norm = max_grad_norm
+        self._norm_ws = torch.zeros(1026, dtype=torch.float32, device=sync.flat.device)
+        self.last_grad_norm = self._norm_ws[1025]
+
+    def step(self):
+        from . import _lib as L
+        if self.sync._keep or self.sync._unscaled:
+            self.sync.finish(defer_scale=True)
+        gscale = self.sync.take_scale()
+        g = self.param_groups[0]
+        self.step_count += 1
+        mx = float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0
+        L.check(L.lib().m3l_adamw_step(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                       g["weight_decay"], self.step_count, gscale, mx, self._norm_ws.data_ptr(), 1,
+                                       torch.cuda.current_stream().cuda_stream), "m3l_adamw_step")

@@ -454,7 +454,16 @@ class VTMAE(nn.Module):
         return self.encoder.transformer(tokens)
 
     def initialize_training(self, train_args):
-        self.optimizer = optim.AdamW(self.parameters(), lr=train_args['lr'])
+        """pretrain_models.py:673-677.  train_args['fused_optimizer'] (not a reference key, default False): the AdamW update and the
+        clip_grad_norm_(0.5) of train_iterations as m3l_amd.parallel.FlatAdamW over one flat parameter / gradient buffer (one
+        reduction + one update launch per step) instead of torch.optim.AdamW + torch.nn.utils.clip_grad_norm_."""
+        self._fused_opt = bool(train_args.get('fused_optimizer', False))
+        if self._fused_opt:
+            from .parallel import FlatAdamW, GradSync
+            self._opt_sync = GradSync(self)
+            self.optimizer = FlatAdamW(self._opt_sync, lr=train_args['lr'], max_grad_norm=0.5)
+        else:
+            self.optimizer = optim.AdamW(self.parameters(), lr=train_args['lr'])
         self.batch_size = train_args['batch_size']
 
     def train_iterations(self, iterations, replay_buffer, no_tactile=False):
@@ -484,6 +493,7 @@ class VTMAE(nn.Module):
             self.optimizer.zero_grad()
             r_loss = self(xb, use_tactile=not no_tactile)
             r_loss.backward()
-            torch.nn.utils.clip_grad_norm_(self.parameters(), 0.5)
-            self.optimizer.step()
+            if not getattr(self, "_fused_opt", False):
+                torch.nn.utils.clip_grad_norm_(self.parameters(), 0.5)
+            self.optimizer.step()                               # (fused: the clip is part of the update)
         self.eval()

@@ -691,6 +691,71 @@ def test_train_iterations_replay_buffer():
     assert l1 < l0
 
 
+@pytest.mark.parametrize("max_norm", [0.5, 1e6, None])
+def test_fused_adamw_clip_matches_torch(max_norm):
+    """FlatAdamW (m3l_adamw_step: one gradient-norm reduction + one update launch over the flat buffers) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW — the update of VTMAE.train_iterations (pretrain_models.py:675,710) — on the same
+    model, inputs and mask noise over 4 steps: clipping active (0.5), inactive (1e6) and absent; the clipped gradients and the norm as
+    clip_grad_norm_ leaves / returns them."""
+    import copy
+    from m3l_amd.parallel import FlatAdamW, GradSync
+    torch.manual_seed(3)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128)
+    ref = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2).to(DEV)
+    fus = copy.deepcopy(ref)
+    x = {"image": torch.rand(8, 3, 32, 32, device=DEV), "tactile1": torch.rand(8, 3, 16, 16, device=DEV), "tactile2": torch.rand(8, 3, 16, 16, device=DEV)}
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    sync = GradSync(fus)
+    opt_f = FlatAdamW(sync, lr=1e-3, max_grad_norm=max_norm)
+    for it in range(4):
+        noise = [torch.rand(8, 16, device=DEV) for _ in range(3)]
+        opt_r.zero_grad()
+        (ref(x, mask_noise=noise) * 50.0).backward()              # x 50: the norm exceeds 0.5, the clip bites
+        norm_r = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm) if max_norm is not None else None
+        opt_r.step()
+        opt_f.zero_grad()
+        (fus(x, mask_noise=noise) * 50.0).backward()
+        opt_f.step()
+        if max_norm is not None:
+            assert abs(float(opt_f.last_grad_norm) - float(norm_r)) <= 1e-5 * float(norm_r), it
+        gr = dict(ref.named_parameters())
+        for k, p_f in fus.named_parameters():
+            if gr[k].grad is None:
+                continue
+            scale = float(gr[k].detach().abs().max()) + 1e-12
+            assert float((p_f.detach() - gr[k].detach()).abs().max()) <= 2e-5 * scale + 2e-6, (it, k)
+            if max_norm is not None and it == 0:
+                gs = float(gr[k].grad.abs().max()) + 1e-12
+                assert float((p_f.grad - gr[k].grad).abs().max()) <= 1e-4 * gs, ("grad", k)
+
+
+def test_train_iterations_fused_optimizer():
+    """train_args['fused_optimizer']: train_iterations with FlatAdamW (clip fused into the update) lowers the loss like the torch path."""
+    import random
+    torch.manual_seed(0)
+    random.seed(0)
+    rng = np.random.default_rng(0)
+    fs = 2
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=fs).to(DEV)
+    mae.initialize_training({"lr": 1e-3, "batch_size": 8, "fused_optimizer": True})
+    buf = [{"image": rng.random((fs, 32, 32, 3), dtype=np.float32), "tactile": rng.random((fs, 6, 16, 16), dtype=np.float32) * 2 - 1}
+           for _ in range(16)]
+    from m3l_amd import vt_load
+    obs = {"image": np.stack([b["image"] for b in buf]).transpose(0, 2, 3, 1, 4).reshape(16, 32, 32, -1),
+           "tactile": np.stack([b["tactile"] for b in buf]).reshape(16, -1, 16, 16)}
+    xb = vt_load(obs, frame_stack=fs, device=DEV)
+    noises = [torch.rand(16, 16, device=DEV) for _ in range(3)]
+    with torch.no_grad():
+        l0 = float(mae(xb, mask_noise=noises))
+    mae.train_iterations(30, buf)
+    assert not mae.training
+    with torch.no_grad():
+        l1 = float(mae(xb, mask_noise=noises))
+    assert l1 < l0
+
+
 @pytest.mark.parametrize("comm", ["rccl", "c10d"])
 def test_rccl_path_world1_matches_local(comm, monkeypatch):
     """The multi-GPU step (GradSync buckets + chunked transformer backward + RCCL all-reduce on its own stream + FlatAdam)

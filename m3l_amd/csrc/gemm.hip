@@ -303,8 +303,6 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cs[(wr * WM + a * 16 + 4 * g + r) * CSLD + wc * 64 + b * 16 + li] = acc[a][b][r];
-    __syncthreads();
-
     constexpr int CPR = BN / 8, RSTEP = 256 / CPR, ITERS = BM / RSTEP;
     const int cchunk = tid % CPR, r0 = tid / CPR;
     const int col = n0 + cchunk * 8;
@@ -327,6 +325,45 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     const bool f_out32 = GEN ? (epi.out_f32 != nullptr) : (EPI == EPI_RES32);
     const bool f_out_t = GEN ? (out_t != nullptr) : (EPI != EPI_RES32);
     const bool f_colsum = GEN ? (epi.colsum_part != nullptr) : (EPI == EPI_DGELU && epi.colsum_part != nullptr);
+    // The epilogue's row operands (fp32 residual, pre-activation u) of ALL this thread's row segments are requested here, before the
+    // accumulators' trip through LDS: loaded inside the store loop below, segment i's loads came behind segment i - 1's stores, and a
+    // wave's vmcnt covers both kinds — every segment waited for the previous segment's HBM write as well as for its own read (four
+    // dependent round trips per 128-row tile).  Rows past M read row M - 1 (dropped).
+    f32x4 rq0[ITERS], rq1[ITERS];
+    Frag<T> ruu[ITERS];
+    if (col_ok && (f_res || f_gelu_u)) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const long o = (long)min(m0 + r0 + RSTEP * i, M - 1) * epi.ldc + col;
+            if (f_res) {
+                rq0[i] = *reinterpret_cast<const f32x4*>(epi.res + o);
+                rq1[i] = *reinterpret_cast<const f32x4*>(epi.res + o + 4);
+            }
+            if (f_gelu_u) {
+                if constexpr (sizeof(T) == 2) {
+                    ruu[i].v = *reinterpret_cast<const bf16x8*>(gelu_u + o);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ruu[i].v[j] = gelu_u[o + j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // gelu'(u) of every segment before the first store, in straight-line code: the segments below are basic blocks of their own (the row
+    // guard), and at each block entry the compiler must assume the loads above still pending next to the previous block's store -> vmcnt(0)
+    float gfac[GEN || EPI == EPI_DGELU ? ITERS : 1][8];
+    if (col_ok && f_gelu_u) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = gelu_grad_t<T>(to_f32(ruu[i].v[j]));
+                asm volatile("" : "+v"(f));                    // evaluated HERE (left alone the compiler sinks it into the segment that uses it)
+                gfac[GEN || EPI == EPI_DGELU ? i : 0][j] = f;
+            }
+    }
     if (col_ok) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
@@ -341,15 +378,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * epi.alpha + bias[j];
             if (f_gelu_u) {
-                Frag<T> uu;
-                if constexpr (sizeof(T) == 2) {
-                    uu.v = *reinterpret_cast<const bf16x8*>(gelu_u + o);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) uu.v[j] = gelu_u[o + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_t<T>(to_f32(uu.v[j]));
+                for (int j = 0; j < 8; ++j) v[j] *= gfac[GEN || EPI == EPI_DGELU ? i : 0][j];
             }
             if (f_out_pre) {
                 Frag<T> pk;
@@ -378,8 +408,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
                 for (int j = 0; j < 8; ++j) v[j] = to_f32(rr[o + j]) > 0.f ? v[j] : 0.f;
             }
             if (f_res) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(epi.res + o);
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(epi.res + o + 4);
+                const f32x4 q0 = rq0[i], q1 = rq1[i];
                 v[0] += q0[0]; v[1] += q0[1]; v[2] += q0[2]; v[3] += q0[3];
                 v[4] += q1[0]; v[5] += q1[1]; v[6] += q1[2]; v[7] += q1[3];
             }

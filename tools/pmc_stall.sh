@@ -8,13 +8,15 @@ export M3L_WGRAD_INLINE=1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/p -o p -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 2 > $OUT/log.txt 2>&1
 cd $R
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 fs = glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for f in fs:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = k.split("(")[0][-70:]
+        m = re.search(r"(\w+_kernel)(<[^>]*>|I[\w]*?E(?=v|E))?", k)
+        k = (m.group(1) + (m.group(2) or "")) if m else k[:60]
+        k = k[:70]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 rows = []
 for k, d in acc.items():

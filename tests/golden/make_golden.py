@@ -262,6 +262,46 @@ def run_ppo_like(ref):
     print("ppo_like_step: losses", losses)
 
 
+def run_train_iterations(ref):
+    """`VTMAE.initialize_training` + `VTMAE.train_iterations` themselves (models/pretrain_models.py:673-715): AdamW(lr) +
+    clip_grad_norm_(0.5) over batches that `random.choices` draws from a replay buffer, one iteration per call, twice.  Records the
+    buffer, the drawn indices (the same `random` seed gives them to a replacement), the mask noise and the weights after each iteration,
+    so the second optimizer form of the path is pinned to the reference's own code."""
+    import random
+    torch.manual_seed(71)
+    fs, bs, nbuf = 2, 4, 6
+    enc = ref.VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+                  image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = ref.VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2,
+                    early_conv_masking=False, use_sincosmod_encodings=True, frame_stack=fs)
+    mae.initialize_training({"lr": 1e-3, "batch_size": bs})
+    rng = np.random.default_rng(72)
+    buf = [{"image": rng.random((fs, 32, 32, 3), dtype=np.float32) * 40.0,       # x 40: the gradient norm exceeds 0.5, the clip bites
+            "tactile": (rng.random((fs, 6, 16, 16), dtype=np.float32) * 2 - 1)} for _ in range(nbuf)]
+    out = {"param0/" + k: v.detach().clone().numpy() for k, v in mae.state_dict().items()}
+    for i, b in enumerate(buf):
+        out[f"buf/{i}/image"], out[f"buf/{i}/tactile"] = b["image"], b["tactile"]
+    g = torch.Generator().manual_seed(73)
+    random.seed(74)
+    st = random.getstate()
+    out["choices"] = np.array([random.choices(range(nbuf), k=bs) for _ in range(2)], dtype=np.int64)
+    random.setstate(st)
+    keys = ("to_pixels.weight", "to_tactiles.bias", "encoder.transformer.layers.0.0.to_qkv.weight", "mask_token",
+            "encoder.image_to_patch_embedding.2.bias", "decoder.layers.0.1.net.1.weight", "encoder.transformer.norm.weight")
+    for it in range(2):
+        noises = [_noise(g, bs, 16) for _ in range(3)]
+        for j, nz in enumerate(noises):
+            out[f"noise/{it}/{j}"] = nz.numpy()
+        with _RandQueue(noises):
+            mae.train_iterations(1, buf)
+        for k in keys:
+            out[f"iter{it}/" + k] = dict(mae.named_parameters())[k].detach().clone().numpy()
+    out["meta"] = np.array([32, 16, 8, 4, 64, 1, 2, 128, 3 * fs, 2, 64, 1, 2, bs], dtype=np.int64)
+    out["frame_stack"] = np.array(fs)
+    np.savez_compressed(os.path.join(HERE, "train_iterations.npz"), **out)
+    print("train_iterations: |to_pixels.weight| after", [float(np.abs(out[f"iter{it}/to_pixels.weight"]).sum()) for it in range(2)])
+
+
 def run_extractor(ref):
     """`MAEExtractor.forward` (models/pretrain_models.py:788-841), the policy-side consumer: frame-stacked observations -> vt_load ->
     get_embeddings(eval=False) -> 1-layer Transformer -> mean over tokens.  The SB3 base class is an inert nn.Module stub."""
@@ -485,6 +525,9 @@ def main():
     if "--ppo-only" in sys.argv:
         run_ppo_like(ref)
         return
+    if "--trainiter-only" in sys.argv:
+        run_train_iterations(ref)
+        return
     if "--block-only" in sys.argv:
         run_block_stack()
         return
@@ -505,6 +548,7 @@ def main():
     if "--reconstruct-only" not in sys.argv:
         _main_cases(ref)
         run_ppo_like(ref)
+        run_train_iterations(ref)
         run_extractor(ref)
         run_dino_cat_extractor()
     # F: reconstruct(): count rule int(r*n) (0.7*16 -> 11 image, 11 per sensor), both masking modes, default + vision-only

@@ -239,6 +239,36 @@ def test_ppo_like_update_with_adam(golden_dir):
             np.testing.assert_allclose(P[k].detach().numpy(), z[f"step{i}/{k}"], rtol=2e-4, atol=2e-6, err_msg=k)
 
 
+def test_train_iterations_adamw_clip(golden_dir):
+    """The reference's VTMAE.initialize_training + train_iterations (models/pretrain_models.py:673-715: random.choices from a replay
+    buffer -> stack -> vt_load -> loss -> backward -> clip_grad_norm_(0.5) -> AdamW.step), one iteration per call, twice: the oracle +
+    torch's clip_grad_norm_ + torch.optim.AdamW reproduce the weights after each iteration (the clip is active: image values up to 40)."""
+    z = _load(golden_dir, "train_iterations")
+    fs = int(z["frame_stack"])
+    cfg = O.cfg_from_meta(z["meta"], 0.75)
+    P = {k[len("param0/"):]: torch.tensor(z[k]).clone().requires_grad_(torch.tensor(z[k]).dtype.is_floating_point)
+         for k in z.files if k.startswith("param0/")}
+    trainable = [k for k, v in P.items() if v.requires_grad and not k.endswith("pos_embedding") and "pos_emb" not in k]
+    opt = torch.optim.AdamW([P[k] for k in trainable], lr=1e-3)
+    nbuf = len([k for k in z.files if k.startswith("buf/") and k.endswith("/image")])
+    for it in range(2):
+        idx = z["choices"][it]
+        img = np.stack([z[f"buf/{j}/image"] for j in idx]).transpose(0, 2, 3, 1, 4)
+        img = img.reshape(img.shape[0], img.shape[1], img.shape[2], -1)
+        tac = np.stack([z[f"buf/{j}/tactile"] for j in idx])
+        tac = tac.reshape(tac.shape[0], -1, tac.shape[3], tac.shape[4])
+        opt.zero_grad()
+        x = O.vt_load({"image": img, "tactile": tac}, frame_stack=fs)
+        noises = [torch.tensor(z[f"noise/{it}/{j}"]) for j in range(3)]
+        O.vtmae_forward(P, cfg, x, noises)["loss"].backward()
+        norm = torch.nn.utils.clip_grad_norm_([P[k] for k in trainable], 0.5)
+        assert float(norm) > 0.5                                   # the clip bites
+        opt.step()
+        for k in [f[len(f"iter{it}/"):] for f in z.files if f.startswith(f"iter{it}/")]:
+            np.testing.assert_allclose(P[k].detach().numpy(), z[f"iter{it}/{k}"], rtol=2e-4, atol=2e-6, err_msg=k)
+    assert nbuf == 6
+
+
 @pytest.mark.parametrize("tag", ["vt", "vision_only"])
 def test_mae_extractor(golden_dir, tag):
     """The reference's MAEExtractor.forward (models/pretrain_models.py:788-841): vt_load -> get_embeddings -> 1-layer Transformer ->

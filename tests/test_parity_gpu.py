@@ -1009,6 +1009,50 @@ def test_ppo_like_update_golden(golden_dir, optimizer):
             np.testing.assert_allclose(named[k].detach().cpu().numpy(), z[f"step{i}/{k}"], rtol=1e-3, atol=1e-5, err_msg=k)
 
 
+class _RandQueue:
+    """torch.rand(...) pops pre-generated noise (as tests/golden/make_golden.py injects it into the reference)."""
+
+    def __init__(self, noises):
+        self.noises, self.real = list(noises), torch.rand
+
+    def __enter__(self):
+        def fake(*shape, device=None, **kw):
+            n = self.noises.pop(0)
+            assert tuple(n.shape) == tuple(shape), (n.shape, shape)
+            return n.clone().to(device) if device is not None else n.clone()
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self.real
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_train_iterations_golden(golden_dir, fused):
+    """VTMAE.initialize_training + train_iterations against the reference's OWN run of them (models/pretrain_models.py:673-715,
+    tests/golden/train_iterations.npz): the same `random` seed draws the same batches from the same replay buffer, the same mask noise is
+    injected, and the weights after each of two iterations must agree — with torch.optim.AdamW + clip_grad_norm_ (the reference's calls)
+    and with the fused FlatAdamW (train_args['fused_optimizer']: one gradient-norm reduction + one update launch)."""
+    import random
+    z = np.load(os.path.join(golden_dir, "train_iterations.npz"))
+    fs = int(z["frame_stack"])
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=1, heads=2, mlp_dim=128,
+              image_channels=3 * fs, tactile_channels=3 * fs, num_tactiles=2, frame_stack=fs)
+    mae = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, num_tactiles=2, frame_stack=fs)
+    mae.load_state_dict({k[len("param0/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param0/")}, strict=True)
+    mae = mae.to(DEV)
+    mae.initialize_training({"lr": 1e-3, "batch_size": 4, "fused_optimizer": fused})
+    buf = [{"image": z[f"buf/{i}/image"], "tactile": z[f"buf/{i}/tactile"]} for i in range(6)]
+    random.seed(74)
+    for it in range(2):
+        noises = [torch.tensor(z[f"noise/{it}/{j}"]) for j in range(3)]
+        with _RandQueue(noises):
+            mae.train_iterations(1, buf)
+        named = dict(mae.named_parameters())
+        for k in [f[len(f"iter{it}/"):] for f in z.files if f.startswith(f"iter{it}/")]:
+            np.testing.assert_allclose(named[k].detach().cpu().numpy(), z[f"iter{it}/{k}"], rtol=2e-3, atol=2e-5, err_msg=f"{it} {k}")
+
+
 @pytest.mark.parametrize("tag", ["vt", "vision_only"])
 def test_mae_extractor_golden(golden_dir, tag):
     """m3l_amd.MAEExtractor against the reference's own MAEExtractor.forward (models/pretrain_models.py:788-841): features and the

@@ -1187,8 +1187,11 @@ static int wide_min_rows(int D) {
     if (D == 384 && on384 <= 0 && v <= 0) return 1 << 30;
     return v > 0 ? v : 128 * 16 * (D == 256 ? WideTile<256>::TT : WideTile<384>::TT);
 }
+// the row-bounded stores (rows_rsrc / store_row16) address a matrix through a 32-bit byte offset: the fp32 [M, D] row matrices must
+// stay below 2 GiB with a tile of slack (every reference configuration is three orders of magnitude smaller; past it: the per-op path)
+static bool rows_fit_32bit(int D, int M) { return ((long)M + 256) * D * 4 < 2147483647L; }
 int m3l_mlp_t192_supported(int dtype, int D, int mlp, int M) {
-    if (!(t192_state() > 0 && dtype == 1 && width_ok(D) && mlp % 32 == 0 && mlp >= 32 && M > 0)) return 0;
+    if (!(t192_state() > 0 && dtype == 1 && width_ok(D) && mlp % 32 == 0 && mlp >= 32 && M > 0 && rows_fit_32bit(D, M))) return 0;
     if (D == 192) return mlp <= 1024;
     return mlp <= 2048 && (M >= wide_min_rows(D) || forced());
 }
@@ -1299,7 +1302,7 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
 }
 
 int m3l_qkv_bwd_t192_supported(int dtype, int D, int K, int M) {
-    if (!(t192_state() > 0 && dtype == 1 && width_ok(D) && K % 64 == 0 && K >= 64 && M > 0)) return 0;
+    if (!(t192_state() > 0 && dtype == 1 && width_ok(D) && K % 64 == 0 && K >= 64 && M > 0 && rows_fit_32bit(D, M))) return 0;
     if (D == 192) return cdiv(M, 192) >= t192_min_tiles() || forced();   // bit 4: any M (tests)
     return M >= wide_min_rows(D) || forced();
 }

@@ -134,13 +134,19 @@ def secondary_workloads(dtype, dev, names=("cfg4", "cfg5", "ref"), steps=10, war
             return loss
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        rows[name] = {"workload": desc, "batch": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+        # three windows of `steps` steps, the median one reported: a single host / allocator hiccup of a few tens of ms inside a 20-60 ms
+        # window otherwise halves a figure (seen once in a while on the pool's boxes; the headline measurement keeps the contract's
+        # single K-step window)
+        els = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
+        rows[name] = {"workload": desc, "batch": B, "steps": steps, "windows": 3, "ms_per_step": round(el / steps * 1e3, 3),
                       "samples_per_s": round(B * steps / el, 1), "model_tflops": round(3 * fwd_flops_per_sample(c) * B * steps / el / 1e12, 1),
                       "loss": round(float(loss.detach()), 5)}
         del mae, sync, opt, x

@@ -415,6 +415,24 @@ def main():
         prof_json = prof_files[-1] if prof_files else ""
         prof_name = os.path.join("profiles", os.path.basename(prof_json)) if prof_json else None
         prof = json.load(open(prof_json)) if prof_json else {}
+        # what code the quoted profile was measured on, against what runs now (a stale profile must not feed a fresh
+        # line silently): the profile tools copy m3l_amd/lib/build_stamp.json (git HEAD at build time + hash of the kernel sources) into
+        # the files they write; this run recomputes the hash of the sources it was built from
+        try:
+            import __graft_entry__ as GE
+            cur_sha = GE.sources_sha16()
+        except Exception:      # noqa: BLE001  (diagnostic field only)
+            cur_sha = None
+        try:
+            cur_stamp = json.load(open(os.path.join(ROOT, "m3l_amd", "lib", "build_stamp.json")))
+        except (OSError, ValueError):
+            cur_stamp = {}
+
+        def prof_meta(p):
+            m = p.get("_meta") or {}
+            return {"profile_git_head": m.get("git_head"), "profile_git_dirty": m.get("git_dirty"), "profile_sources_sha16": m.get("sources_sha16"),
+                    "run_sources_sha16": cur_sha, "run_git_head": cur_stamp.get("git_head") if cur_stamp.get("sources_sha16") == cur_sha else None,
+                    "same_kernel_sources": (m.get("sources_sha16") == cur_sha) if (m.get("sources_sha16") and cur_sha) else None}
         if kinds:
             kname, (ms_tot, launches, work, byt) = max(kinds.items(), key=lambda kv: kv[1][0])
             raw_us = ms_tot / launches * 1e3
@@ -424,6 +442,7 @@ def main():
             traffic = prof.get("wgrad_grouped" if kname == "wgrad" else kname, prof.get(kname, {})).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": kfull, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(gbs / 8000.0, 4), "traffic": traffic,
+                               "traffic_profile": prof_meta(prof) if traffic else None,
                                "traffic_source": f"{prof_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU lease (not re-measured in this run), the same launch population as `achieved` (grouped launches only)" if traffic else None,
                                "algorithmic_bytes_per_launch": round(byt / launches), "avg_launch_us": round(avg_s * 1e6, 2),
                                "avg_bracket_us_raw": round(raw_us, 2), "event_bracket_overhead_us": round(ev_overhead_us, 2),
@@ -453,7 +472,7 @@ def main():
         if prof.get("_step"):
             sb = prof["_step"]["hbm_bytes_per_step"]
             out["step_hbm"] = {"bytes_per_step": sb, "GBps": round(sb / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(sb / (ms * 1e-3) / 8e12, 4),
-                               "source": f"{prof_name} (PMC, builder's lease) / this run's ms_per_step"}
+                               "source": f"{prof_name} (PMC, builder's lease) / this run's ms_per_step", "profile": prof_meta(prof)}
             out["top_kernels"] = prof["_step"].get("top_kernels")
         total_flops = 3 * fwd_flops_per_sample(c) * value
         out["model_tflops"] = round(total_flops / 1e12, 2)
@@ -472,7 +491,8 @@ def main():
                 "whole_attention_block_util": ph.get("kernel_mfma_util_useful"), "target": 0.40,
                 "bound": "~0.27 at the HBM roof: one encoder layer is 4.1 GFLOP (256 samples x 48 visible tokens) = 1.6 us at the bf16 peak, and with every "
                          "activation saved for the backward the block moves ~86 FLOP per byte",
-                "source": os.path.join("profiles", os.path.basename(ph_files[-1])) + " (in-kernel shader-clock stamps, not re-measured in this run)"}
+                "source": os.path.join("profiles", os.path.basename(ph_files[-1])) + " (in-kernel shader-clock stamps, not re-measured in this run)",
+                "profile": prof_meta(ph)}
         if world == 1 and not args.no_secondary and args.workload == "cfg2":
             out["secondary"] = secondary_workloads(args.dtype, dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":

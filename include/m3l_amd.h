@@ -298,6 +298,12 @@ int m3l_op_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, in
 size_t m3l_op_gemm_tn_ws_bytes(int M, int N, int K);
 int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, int M, int N, int K, void* ws, size_t ws_bytes,
                    float* out, int ldo, void* stream);
+/* `count` weight gradients that share M in ONE grouped launch (what a transformer layer group's backward issues: dW_i [N_i, K_i] = Y_i^T X_i,
+ * every nn.Linear.weight.grad of vit_pytorch Attention / FeedForward via loss.backward(), models/ppo_mae.py:263); bf16 operands take the
+ * 256 x 192 split-M kernel of wgrad.hip.  Y / X / out: host arrays of device pointers; ld* / N / K: host int arrays. */
+size_t m3l_op_gemm_tn_grouped_ws_bytes(int dtype, int count, int M, const int* N, const int* K);
+int m3l_op_gemm_tn_grouped(int dtype, int count, int M, const void* const* Y, const int* ldy, const void* const* X, const int* ldx, const int* N,
+                           const int* K, float* const* out, void* ws, size_t ws_bytes, void* stream);
 /* building blocks of the trainable fusion MLP of the cfg-5 extractor (models/pretrain_models_dino_cat_mae.py:828-836,899-903: Linear + ReLU +
  * Dropout x 2, Linear, over cat(pooled MAE tokens, DINOv2 feature)): column sums (bias gradients), compute-type + transposed weight copy
  * (dst / dstT may be NULL), keep-mask / ReLU-mask scaling (mode 0: ref = uint8 mask; mode 1: ref = f32, on where ref > 0), and the

@@ -113,6 +113,8 @@ _SIGS = {
     "m3l_op_gemm_nt": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "m3l_op_gemm_tn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "m3l_op_gemm_tn": (c_i, [c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p, c_i, c_p]),
+    "m3l_op_gemm_tn_grouped_ws_bytes": (c_sz, [c_i, c_i, c_i, c_p, c_p]),
+    "m3l_op_gemm_tn_grouped": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "m3l_op_colsum_ws_bytes": (c_sz, [c_i]),
     "m3l_op_colsum": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "m3l_op_prep_weight": (c_i, [c_i, c_p, c_i, c_i, c_p, c_p, c_p]),

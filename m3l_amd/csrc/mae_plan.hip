@@ -1562,6 +1562,25 @@ int m3l_op_gemm_tn(int dtype, const void* Y, int ldy, const void* X, int ldx, in
                    float* out, int ldo, void* stream) {
     return m3l_gemm_tn(dtype, Y, ldy, X, ldx, M, N, K, (float*)ws, ws_bytes, out, ldo, N, K, 0, (hipStream_t)stream);
 }
+size_t m3l_op_gemm_tn_grouped_ws_bytes(int dtype, int count, int M, const int* N, const int* K) {
+    (void)dtype;
+    if (count < 1 || count > M3L_TN_MAX_PROBLEMS || M <= 0 || !N || !K) return 0;
+    TnProblem pr[M3L_TN_MAX_PROBLEMS];
+    memset(pr, 0, sizeof(pr));
+    for (int i = 0; i < count; ++i) { pr[i].N = N[i]; pr[i].K = K[i]; }
+    return m3l_gemm_tn_grouped_ws_bytes(M, pr, count);
+}
+int m3l_op_gemm_tn_grouped(int dtype, int count, int M, const void* const* Y, const int* ldy, const void* const* X, const int* ldx, const int* N,
+                           const int* K, float* const* out, void* ws, size_t ws_bytes, void* stream) {
+    M3L_CHECK(count >= 1 && count <= M3L_TN_MAX_PROBLEMS && Y && X && ldy && ldx && N && K && out && ws, "gemm_tn_grouped: bad arguments (count %d)", count);
+    TnProblem pr[M3L_TN_MAX_PROBLEMS];
+    memset(pr, 0, sizeof(pr));
+    for (int i = 0; i < count; ++i) {
+        pr[i].Y = Y[i]; pr[i].X = X[i]; pr[i].ldy = ldy[i]; pr[i].ldx = ldx[i]; pr[i].N = N[i]; pr[i].K = K[i];
+        pr[i].out = out[i]; pr[i].ldo = K[i]; pr[i].nvalid = N[i]; pr[i].kvalid = K[i];
+    }
+    return m3l_gemm_tn_grouped(dtype, pr, count, M, (float*)ws, ws_bytes, 0, (hipStream_t)stream);
+}
 // ---- building blocks of the cfg-5 fusion head's trainable MLP (models/pretrain_models_dino_cat_mae.py:828-836,899-903) ----
 int m3l_op_colsum(int dtype, const void* Y, int M, int N, int ld, void* ws, float* out, void* stream) {
     return m3l_colsum(dtype, Y, M, N, ld, (float*)ws, out, 0, (hipStream_t)stream);

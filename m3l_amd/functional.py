@@ -508,6 +508,21 @@ class MaeStepFn(torch.autograd.Function):
                 sync._sent_end = int(comm[2].value)
                 sync._unscaled = True
             return (None,) * (1 + ctx.n_in)
+        if sync is not None and ctx.n_in == 1:
+            # anchor mode, second backward before zero_grad() (gradient accumulation / the reference's separate_optimizer=False update):
+            # autograd sees one input, so the fresh gradients are added into the flat views here (_grad_targets has joined the side stream)
+            dst, src = [], []
+            for g, t in zip(grads, plan.tensors):
+                if g is None or t is None or not t.requires_grad:
+                    continue
+                if t.grad is None:
+                    t.grad = g
+                else:
+                    dst.append(t.grad)
+                    src.append(g)
+            if dst:
+                torch._foreach_add_(dst, src)
+            return (None,) * (1 + ctx.n_in)
         return (None,) + tuple(g for g, t in zip(grads, plan.tensors) if t is not None)      # the autograd inputs = the non-None tensors
 
 

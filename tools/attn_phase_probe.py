@@ -67,6 +67,10 @@ for nm, c in zip(names, cyc):
         e["mfma_util_useful"] = round(useful[nm] / (c * PEAK), 4)
     out["phases"][nm] = e
 out["kernel_mfma_util_useful"] = round(sum(useful.values()) / (tot * PEAK), 4)
+try:
+    out["_meta"] = json.load(open(os.path.join(ROOT, "m3l_amd", "lib", "build_stamp.json")))
+except (OSError, ValueError):
+    out["_meta"] = {}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for path in (os.path.join(ROOT, "gpurun_out", f"{tag}_attn_phases.json"),):
     json.dump(out, open(path, "w"), indent=1)

@@ -128,5 +128,9 @@ if st:
         top.append({"kernel": key, "share_of_kernel_time": round(float(r["TotalDurationNs"]) / ktot, 4), "avg_us": round(avg_us, 1),
                     "hbm_bytes_per_launch": b, "hbm_frac_of_8TBps": round(b / (avg_us * 1e-6) / 8e12, 4) if b else None})
     traffic["_step"]["top_kernels"] = top
+try:      # what code these counters were collected on (bench.py shows it beside every figure it quotes from this file)
+    traffic["_meta"] = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "m3l_amd", "lib", "build_stamp.json")))
+except (OSError, ValueError):
+    traffic["_meta"] = {}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_step")) if isinstance(v, dict) else v) for k, v in traffic.items()}))

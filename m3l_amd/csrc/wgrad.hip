@@ -26,9 +26,6 @@
 
 namespace {
 
-constexpr int WG_THREADS = 512;
-constexpr int WG_TA = 256;
-
 typedef int int4v __attribute__((ext_vector_type(4)));
 
 struct WgProb {
@@ -91,67 +88,92 @@ __device__ __forceinline__ Frag<bf16> ldtr(const char* panel, int k0, int c0, in
     return f;
 }
 
-constexpr int WG_NST = 4;                    // ring stages of 32 rows x 8 panels (32 KiB): three stages requested ahead
-constexpr int WG_STAGE = 8 * 4096;
+#ifndef WG_ABL
+#define WG_ABL 0            // diagnostic builds only (tools/t192_ablate.sh "..." wgrad WG_ABL): 1 no MFMAs, 2 no fragment reads either, 4 no DMA, 8 no slab stores
+#endif
+constexpr int WG_NST = 4;                    // ring stages of 32 rows: three stages requested ahead
 
-template <int TBT>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs, int nt) {
-    constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
+// wait until at most n of this wave's vector-memory operations remain outstanding (n is wave-uniform, 0 .. 8: up to two stages of up to
+// four pieces each may stay in flight)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// Tile = 64 NA (wide operand) x 64 TBT (narrow operand) outputs, 2 NA waves of 64 x 32 TBT each.  <4, *>: 256-wide, 8 waves (2 per SIMD,
+// up to 183 VGPRs).  <6, 3>: 384 x 192, 12 waves (3 per SIMD, 149 VGPRs): the ViT-Tiny layer (every weight has a 192 dimension) as
+// 2 + 2 + 2 + 1 tiles instead of 3 + 3 + 3 + 1 — the narrow operand is staged once per TWO thirds of the wide one, 3648 instead of 4480
+// staged columns per token row against 3072 unique ones — and panels of the wide operand that lie outside the problem (the second
+// tile of the 576-wide qkv gradient holds 192 columns, the out-projection's 192 of 384) are neither staged nor multiplied: their waves
+// only keep the barriers.
+template <int NA, int TBT, bool NTL>
+__global__ __launch_bounds__(128 * NA) void wgrad_kernel(WgGroup grp, int M, int rows_per_split, int nsplit, float* __restrict__ slabs, int per_xcd) {
+    constexpr int TA = 64 * NA, TB = 64 * TBT, NB = TB / 32, NT = 4 * NB, NW = 2 * NA;
+    constexpr int SLOT = (NA + TBT) * 4096, P = 4 * (NA + TBT), JMAX = (P + NW - 1) / NW;
+    static_assert(JMAX <= 4, "at most four pieces per wave and stage (wait_vm)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware order: the tiles of one row range read the same rows of their operands -> ids that differ by multiples of 8
-    const int bid = blockIdx.x, rest = bid >> 3;
-    const int gtile = rest % grp.tiles_total, sp = (rest / grp.tiles_total) * 8 + (bid & 7);
-    if (sp >= nsplit) return;
+    // Work list in split-major order (w = split * tiles + tile: neighbours read the same token rows), cut into 8 contiguous chunks, chunk x
+    // handed to the blocks with id = x (mod 8), which share an XCD (and its L2) under the round-robin placement: balanced to one workgroup
+    // for ANY split count (the earlier map gave split sp to XCD sp mod 8: 80 workgroups on one XCD and 60 on the others at 25 splits)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int W = grp.tiles_total * nsplit, w = xcd * per_xcd + idx;
+    if (w >= W || w >= (xcd + 1) * per_xcd) return;
+    const int gtile = w % grp.tiles_total, sp = w / grp.tiles_total;
     int pi = 0;
     for (int i = 1; i < grp.count; ++i)
         if (gtile >= grp.p[i].tile0) pi = i;
     const WgProb& pb = grp.p[pi];
     const int tile = gtile - pb.tile0;
-    const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
+    const int a0 = (tile / pb.tiles_b) * TA, b0 = (tile % pb.tiles_b) * TB;
     const int m_beg = sp * rows_per_split;
     const int m_end = min(M, m_beg + rows_per_split);
     const int nst = (m_end - m_beg + 31) >> 5;               // 32-row stages
 
     const int4v rsA = make_rsrc(pb.A, (long)M * pb.lda * 2), rsB = make_rsrc(pb.B, (long)M * pb.ldb * 2);
-    // A stage image = 4 + TBT panels of [32 rows][128 B] (panels 0..3 = A, 4.. = B) in a 32-KiB slot.  Waves 0..3 stage one A panel
-    // each (4 pieces: its four 8-row groups); waves 4..7 stage 8-row group (wave - 4) of every B panel (TBT pieces): the counted
-    // waits below use each wave's own piece count.
-    const bool wave_a = wave < 4;                             // wave-uniform
-    unsigned voff[4], vinc;
-    unsigned pdst[4];
-    {
-        const int ld = wave_a ? pb.lda : pb.ldb;
-        vinc = (unsigned)(32 * ld * 2);
+    // A stage image = NA + TBT panels of [32 rows][128 B] (panels 0 .. NA - 1 = A, then B).  Piece q = (panel q >> 2, 8-row group q & 3);
+    // wave v stages the pieces q = v + NW j that exist and whose panel lies inside the problem: `mine` of them per stage (wave-uniform),
+    // the unit of its counted waits.
+    unsigned voff[JMAX], pdst[JMAX];
+    bool pa[JMAX], pv[JMAX];
+    int mine = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int panel = wave_a ? wave : 4 + j, rg = wave_a ? j : wave - 4;
-            const int row = rg * 8 + (lane >> 3);
-            const int csrc = (lane & 7) ^ (2 * ((row >> 1) & 3));
-            int col = wave_a ? (a0 + 64 * panel + csrc * 8) : (b0 + 64 * j + csrc * 8);
-            col = min(col, (wave_a ? pb.a : pb.b) - 8);       // columns past the operand: any valid chunk (never stored)
-            voff[j] = (unsigned)(((long)(m_beg + row) * ld + col) * 2);
-            pdst[j] = (unsigned)(panel * 4096 + rg * 1024);
-        }
+    for (int j = 0; j < JMAX; ++j) {
+        const int q = wave + NW * j, panel = q >> 2, rg = q & 3;
+        const bool is_a = panel < NA;
+        const int c0 = is_a ? a0 + 64 * panel : b0 + 64 * (panel - NA), width = is_a ? pb.a : pb.b, ld = is_a ? pb.lda : pb.ldb;
+        pa[j] = is_a;
+        pv[j] = q < P && c0 < width;                          // wave-uniform
+        mine += pv[j] ? 1 : 0;
+        const int row = rg * 8 + (lane >> 3);
+        const int csrc = (lane & 7) ^ (2 * ((row >> 1) & 3));
+        const int col = min(c0 + csrc * 8, width - 8);        // chunks past the operand inside a partly valid panel: any valid chunk (never stored)
+        voff[j] = (unsigned)(((long)(m_beg + row) * ld + col) * 2);
+        pdst[j] = (unsigned)(panel * 4096 + rg * 1024);
     }
+    const unsigned incA = (unsigned)(32 * pb.lda * 2), incB = (unsigned)(32 * pb.ldb * 2);
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int t) {
-        const unsigned base = lds0 + (t % WG_NST) * WG_STAGE;
-        if (wave_a) {
+        if (WG_ABL & 4) return;
+        const unsigned base = lds0 + (t % WG_NST) * SLOT;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (nt) dma16<true>(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
-                else dma16<false>(rsA, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TBT; ++j) {
-                if (nt) dma16<true>(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
-                else dma16<false>(rsB, voff[j] + (unsigned)t * vinc, __builtin_amdgcn_readfirstlane(base + pdst[j]));
-            }
+        for (int j = 0; j < JMAX; ++j) {
+            if (!pv[j]) continue;
+            if (pa[j]) dma16<NTL>(rsA, voff[j] + (unsigned)t * incA, __builtin_amdgcn_readfirstlane(base + pdst[j]));
+            else dma16<NTL>(rsB, voff[j] + (unsigned)t * incB, __builtin_amdgcn_readfirstlane(base + pdst[j]));
         }
     };
+    const bool work = a0 + 64 * wr < pb.a;                     // this wave's 64 rows of the output tile exist (wave-uniform)
 
     f32x4 acc[4][NB];
 #pragma unroll
@@ -162,29 +184,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
     for (int t = 0; t < WG_NST - 1 && t < nst; ++t) issue(t);
     for (int t = 0; t < nst; ++t) {
         // this wave's pieces of stage t have landed once at most the pieces of the (up to two) younger stages remain (in-order retire)
-        const int ahead = min(WG_NST - 2, nst - 1 - t);
-        if (wave_a || TBT == 4) {
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (TBT == 3) {
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        wait_vm(min(WG_NST - 2, nst - 1 - t) * mine);
         __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done reading stage t - 1
         asm volatile("" ::: "memory");
         if (t + WG_NST - 1 < nst) issue(t + WG_NST - 1);      // into the slot stage t - 1 occupied
         if (pb.gelu_a | pb.gelu_b) {                          // workgroup-uniform
             // the staged operand is the pre-activation u: h = GELU(u) in place, rounded as the forward rounded it, 8 values per thread
             // and pass (rows past M were staged as zeros: GELU(0) = 0).  The kernel waits on HBM most of its time: the pass hides there.
-            char* base = smem + (t % WG_NST) * WG_STAGE + (pb.gelu_a ? 0 : 4 * 4096);
-            const int bytes = pb.gelu_a ? 4 * 4096 : TBT * 4096, form = pb.gelu_a | pb.gelu_b;
-            for (int off = tid * 16; off < bytes; off += WG_THREADS * 16) {
+            char* base = smem + (t % WG_NST) * SLOT + (pb.gelu_a ? 0 : NA * 4096);
+            const int bytes = pb.gelu_a ? NA * 4096 : TBT * 4096, form = pb.gelu_a | pb.gelu_b;
+            for (int off = tid * 16; off < bytes; off += 64 * NW * 16) {
                 bf16x8 v = *reinterpret_cast<bf16x8*>(base + off);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (bf16)(form == 1 ? gelu_f((float)v[j]) : gelu_fast((float)v[j]));
@@ -193,8 +202,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        const char* As = smem + (t % WG_NST) * WG_STAGE + wr * 4096;
-        const char* Bs = smem + (t % WG_NST) * WG_STAGE + 4 * 4096;
+        if ((WG_ABL & 2) || !work) continue;
+        const char* As = smem + (t % WG_NST) * SLOT + wr * 4096;
+        const char* Bs = smem + (t % WG_NST) * SLOT + NA * 4096;
         Frag<bf16> fa[4], fb[NB];
 #pragma unroll
         for (int x = 0; x < 4; ++x) fa[x] = ldtr(As, 0, x * 16, lane);
@@ -203,14 +213,22 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
             const int col = wc * (TB / 2) + y * 16;
             fb[y] = ldtr(Bs + (col >> 6) * 4096, 0, col & 63, lane);
         }
+        if (WG_ABL & 1) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) asm volatile("" ::"v"(fa[x].v));
+#pragma unroll
+            for (int y = 0; y < NB; ++y) asm volatile("" ::"v"(fb[y].v));
+            continue;
+        }
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < NB; ++y) acc[x][y] = mma16(fa[x], fb[y], acc[x][y]);
     }
+    if (WG_ABL & 8) return;
     // fragment-order slab: [wave][tile x * NB + y][lane] float4 (rows 4 g .. 4 g + 3 of the 16 x 16 tile, column li).  16 x 16 tiles that lie
     // entirely outside the problem (a 192 x 32 conv weight in a 256 x 128 tile: 104 of its 128 tiles) are neither written nor read back
-    float* S = slabs + ((long)sp * grp.tiles_total + gtile) * (long)(WG_TA * TB);
+    float* S = slabs + (long)w * (long)(TA * TB);
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         if (a0 + wr * 64 + x * 16 >= pb.avalid) continue;       // wave-uniform
@@ -222,9 +240,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgGroup grp, int M, i
     }
 }
 
-template <int TBT>
+template <int NA, int TBT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const float* __restrict__ slabs, int S, int accumulate) {
-    constexpr int TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
+    constexpr int TA = 64 * NA, TB = 64 * TBT, NB = TB / 32, NT = 4 * NB;
     const int f = blockIdx.x * 256 + threadIdx.x;
     const int gt = blockIdx.y;
     if (gt >= grp.tiles_total) {
@@ -258,15 +276,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgGroup grp, const fl
         }
         return;
     }
-    if (f >= 64 * TB) return;
+    if (f >= TA / 4 * TB) return;
     int pi = 0;
     for (int i = 1; i < grp.count; ++i)
         if (gt >= grp.p[i].tile0) pi = i;
     const WgProb& pb = grp.p[pi];
     const int tile = gt - pb.tile0;
-    const int a0 = (tile / pb.tiles_b) * WG_TA, b0 = (tile % pb.tiles_b) * TB;
-    const long stride = (long)grp.tiles_total * (WG_TA * TB);
-    const float* P = slabs + (long)gt * (WG_TA * TB) + ((long)f << 2);
+    const int a0 = (tile / pb.tiles_b) * TA, b0 = (tile % pb.tiles_b) * TB;
+    const long stride = (long)grp.tiles_total * (TA * TB);
+    const float* P = slabs + (long)gt * (TA * TB) + ((long)f << 2);
     {   // this thread's 16 x 16 tile lies outside the problem: nothing was written, nothing to add (checked BEFORE the S slab reads)
         const int wt0 = f >> 6, t0 = wt0 % NT, w0 = wt0 / NT;
         if (a0 + (w0 >> 1) * 64 + (t0 / NB) * 16 >= pb.avalid || b0 + (w0 & 1) * (TB / 2) + (t0 % NB) * 16 >= pb.bvalid) return;
@@ -322,26 +340,44 @@ int cu_count() {
 }
 
 struct WgPlanHost {
-    int tbt, tiles_total, S, rows_per_split;
+    int na, tbt, tiles_total, S, rows_per_split;
     size_t ws_bytes;
 };
+// cost of a tiling per token row: the columns its LDS-DMA stream stages (panels outside a problem are not staged) + its MFMA area in
+// units of 256 multiply-accumulates (rows of the wide operand outside a problem are not multiplied, columns of the narrow one are)
+long staged_cols(const TnProblem* probs, int count, int na, int tbt) {
+    long cost = 0;
+    const int TA = 64 * na, TB = 64 * tbt;
+    for (int i = 0; i < count; ++i) {
+        const int a = std::max(probs[i].N, probs[i].K), b = std::min(probs[i].N, probs[i].K);
+        const int ta = cdiv(a, TA), tb = cdiv(b, TB);
+        cost += (long)tb * cdiv(a, 64) * 64 + (long)ta * cdiv(b, 64) * 64;       // every tile stages its valid A panels and its valid B panels
+        cost += (long)cdiv(a, 64) * 64 * tb * TB / 256;
+    }
+    return cost;
+}
 // wide / narrow orientation and tiling of a problem list (the same decisions for the size query and the launch)
 WgPlanHost plan_of(int M, const TnProblem* probs, int count, WgGroup* grp) {
     WgPlanHost pl;
+    // tile shape: the lowest cost; ties -> the smaller tile (fewer idle waves).  <6, 4> does not exist (176 VGPRs at 12 waves).
+    static const int force_na = getenv("M3L_WGRAD_NA") ? atoi(getenv("M3L_WGRAD_NA")) : 0;      // 4 / 6: A/B of the tile heights
+    static const int force_tbt = getenv("M3L_WGRAD_TBT") ? atoi(getenv("M3L_WGRAD_TBT")) : 0;
     long best = -1;
+    pl.na = 4;
     pl.tbt = 3;
-    for (int tbt = 2; tbt <= 4; ++tbt) {
-        long cost = 0;
-        for (int i = 0; i < count; ++i) {
-            const int a = std::max(probs[i].N, probs[i].K), b = std::min(probs[i].N, probs[i].K);
-            cost += (long)cdiv(a, WG_TA) * cdiv(b, 64 * tbt) * tbt;
-        }
-        if (best < 0 || cost <= best) {      // ties: the wider tile (more MACs per staged byte)
-            best = cost;
-            pl.tbt = tbt;
+    for (int na = 4; na <= 6; na += 2) {
+        if (force_na && na != force_na) continue;
+        for (int tbt = 2; tbt <= (na == 6 ? 3 : 4); ++tbt) {
+            if (force_tbt && tbt != force_tbt && !(na == 6 && force_tbt == 4)) continue;
+            const long cost = staged_cols(probs, count, na, tbt);
+            if (best < 0 || cost < best) {
+                best = cost;
+                pl.na = na;
+                pl.tbt = tbt;
+            }
         }
     }
-    const int TB = 64 * pl.tbt;
+    const int TA = 64 * pl.na, TB = 64 * pl.tbt;
     int tiles = 0;
     for (int i = 0; i < count; ++i) {
         const TnProblem& p = probs[i];
@@ -360,18 +396,46 @@ WgPlanHost plan_of(int M, const TnProblem* probs, int count, WgGroup* grp) {
             w.gelu_a = y_wide ? 0 : p.gelu_x;        // X is the wide operand when K > N
             w.gelu_b = y_wide ? p.gelu_x : 0;
         }
-        tiles += cdiv(a, WG_TA) * tb;
+        tiles += cdiv(a, TA) * tb;
     }
     pl.tiles_total = tiles;
-    // splits over M: M3L_WGRAD_WAVES workgroups per CU in all (1 = one wave of workgroups, each as long as the launch; 2, the default = shorter
-    // workgroups that hand their CU back to the critical path sooner, at the price of more partial slabs)
-    static const int waves = getenv("M3L_WGRAD_WAVES") ? std::max(1, atoi(getenv("M3L_WGRAD_WAVES"))) : 2;
+    // splits over M: M3L_WGRAD_WAVES workgroups per CU in all.  1 (the default since round 4) = one wave of workgroups, each as long as the
+    // launch: half the partial slabs of 2.  (Round 2-3 ran 2: with the split -> XCD map of that kernel one wave left XCDs 0-3 with twice
+    // the workgroups of XCDs 4-7; with the balanced work list one wave is 126 us per grouped launch in-step against 160 for two, 105
+    // against 113 stand-alone, and the step gains 1 %.)
+    static const int waves = getenv("M3L_WGRAD_WAVES") ? std::max(1, atoi(getenv("M3L_WGRAD_WAVES"))) : 1;
     int S = std::max(1, waves * cu_count() / std::max(1, tiles));
     S = std::min(S, std::max(1, M / 256));                     // at least 256 rows per split
     pl.rows_per_split = cdiv(cdiv(M, S), 64) * 64;
     pl.S = cdiv(M, pl.rows_per_split);
-    pl.ws_bytes = (size_t)pl.S * tiles * WG_TA * TB * sizeof(float);
+    pl.ws_bytes = (size_t)pl.S * tiles * TA * TB * sizeof(float);
     return pl;
+}
+
+template <int NA, int TBT>
+int launch_wgrad(const WgGroup& grp, const WgPlanHost& pl, int M, float* ws, int accumulate, int maxw, int extra_count, hipStream_t st, int count,
+                 double flops, double bytes, int nt) {
+    constexpr int TA = 64 * NA, TB = 64 * TBT;
+    constexpr size_t lds = (size_t)WG_NST * (NA + TBT) * 4096;
+    static bool inited = false;
+    if (!inited) {
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<NA, TBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<NA, TBT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        inited = true;
+    }
+    {
+        ProfScope prof(count >= 3 ? "wgrad" : "wgrad_small", M, pl.tiles_total, pl.S, flops, st, bytes);   // grouped layer launches vs single Linears
+        const int per_xcd = cdiv((long)pl.tiles_total * pl.S, 8);
+        const dim3 g1(8 * per_xcd);
+        if (nt) wgrad_kernel<NA, TBT, true><<<g1, 128 * NA, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, per_xcd);
+        else wgrad_kernel<NA, TBT, false><<<g1, 128 * NA, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, per_xcd);
+    }
+    M3L_LAUNCH_CHECK();
+    ProfScope prof2("wgrad_reduce", pl.S, pl.tiles_total, count, 0.0, st, (double)pl.ws_bytes);
+    const dim3 g2(std::max(cdiv(TA / 4 * TB, 256), cdiv(maxw, 32)), pl.tiles_total + extra_count);
+    wgrad_reduce_kernel<NA, TBT><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
+    M3L_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -386,13 +450,6 @@ int m3l_wgrad_layers_per_launch(int M, const TnProblem* layer_probs, int count) 
 
 int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_bytes, int accumulate, hipStream_t st, const TnExtra* extras,
                    int extra_count) {
-    static int inited = 0;
-    if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
-        M3L_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NST * WG_STAGE));
-        inited = 1;
-    }
     M3L_CHECK(count >= 1 && count <= M3L_TN_MAX_PROBLEMS && M > 0, "wgrad: count=%d M=%d", count, M);
     M3L_CHECK(extra_count >= 0 && extra_count <= M3L_TN_MAX_EXTRAS, "wgrad: %d extra reductions", extra_count);
     WgGroup grp;
@@ -416,22 +473,12 @@ int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_byte
         maxw = std::max(maxw, extras[i].width);
     }
     M3L_CHECK(ws_bytes >= pl.ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
-    const int TB = 64 * pl.tbt;
     static const int wg_nt = getenv("M3L_WGRAD_NT") ? atoi(getenv("M3L_WGRAD_NT")) : 0;     // opt-in: non-temporal operand loads (stand-alone 136 -> 126 us, nothing end to end)
-    {
-        ProfScope prof(count >= 3 ? "wgrad" : "wgrad_small", M, pl.tiles_total, pl.S, flops, st, bytes);   // grouped layer launches vs single Linears
-        const dim3 g1(8 * pl.tiles_total * cdiv(pl.S, 8));
-        const size_t lds = (size_t)WG_NST * WG_STAGE;
-        if (pl.tbt == 2) wgrad_kernel<2><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
-        else if (pl.tbt == 3) wgrad_kernel<3><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
-        else wgrad_kernel<4><<<g1, WG_THREADS, lds, st>>>(grp, M, pl.rows_per_split, pl.S, ws, wg_nt);
+    if (pl.na == 6) {
+        if (pl.tbt == 2) return launch_wgrad<6, 2>(grp, pl, M, ws, accumulate, maxw, extra_count, st, count, flops, bytes, wg_nt);
+        return launch_wgrad<6, 3>(grp, pl, M, ws, accumulate, maxw, extra_count, st, count, flops, bytes, wg_nt);
     }
-    M3L_LAUNCH_CHECK();
-    ProfScope prof2("wgrad_reduce", pl.S, pl.tiles_total, count, 0.0, st, (double)pl.ws_bytes);
-    const dim3 g2(std::max(cdiv(64 * TB, 256), cdiv(maxw, 32)), pl.tiles_total + extra_count);
-    if (pl.tbt == 2) wgrad_reduce_kernel<2><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
-    else if (pl.tbt == 3) wgrad_reduce_kernel<3><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
-    else wgrad_reduce_kernel<4><<<g2, 256, 0, st>>>(grp, ws, pl.S, accumulate);
-    M3L_LAUNCH_CHECK();
-    return 0;
+    if (pl.tbt == 2) return launch_wgrad<4, 2>(grp, pl, M, ws, accumulate, maxw, extra_count, st, count, flops, bytes, wg_nt);
+    if (pl.tbt == 3) return launch_wgrad<4, 3>(grp, pl, M, ws, accumulate, maxw, extra_count, st, count, flops, bytes, wg_nt);
+    return launch_wgrad<4, 4>(grp, pl, M, ws, accumulate, maxw, extra_count, st, count, flops, bytes, wg_nt);
 }

@@ -99,6 +99,36 @@ def test_gemm_tn(dev, code, M, N, K):
     assert (out - ref).abs().max().item() <= (2e-3 if code else 2e-5) * ref.abs().max().item() + 1e-4
 
 
+@pytest.mark.parametrize("M,shapes", [
+    (777, [(192, 768), (768, 192), (576, 192), (192, 192)] * 2),                 # two ViT-Tiny layers (the 384 x 192 tiles: 2 + 2 + 2 + 1 per layer, half-empty tiles), ragged M
+    (5000, [(256, 512), (512, 256), (768, 256), (256, 256)]),                    # M3L's default width (256 x 256 tiles)
+    (1030, [(384, 1536), (1536, 384), (1152, 384), (384, 384)]),                 # ViT-Small layer
+    (2100, [(192, 768), (64, 32), (8, 200), (264, 136), (192, 48)]),             # mixed: transformer weights beside small / odd ones
+    (12288, [(192, 768), (768, 192), (576, 192), (192, 192)] * 4),               # the encoder's four-layer group of cfg 2
+])
+def test_gemm_tn_grouped(dev, M, shapes):
+    """Grouped weight gradients dW_i = Y_i^T X_i through ONE launch (wgrad.hip via m3l_op_gemm_tn_grouped) against torch, bf16 operands:
+    every nn.Linear.weight.grad of a transformer layer group (vit_pytorch Attention / FeedForward via loss.backward(), ppo_mae.py:263)."""
+    import ctypes as C
+    torch.manual_seed(M)
+    cnt = len(shapes)
+    Ys = [(0.5 * torch.randn(M, n, device=dev)).to(torch.bfloat16) for n, _ in shapes]
+    Xs = [(0.5 * torch.randn(M, k, device=dev)).to(torch.bfloat16) for _, k in shapes]
+    outs = [torch.full((n, k), float("nan"), device=dev) for n, k in shapes]
+    Ns, Ks = (C.c_int * cnt)(*[n for n, _ in shapes]), (C.c_int * cnt)(*[k for _, k in shapes])
+    nb = L.lib().m3l_op_gemm_tn_grouped_ws_bytes(1, cnt, M, Ns, Ks)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    for rep in range(2):            # twice: bit-reproducible (fixed-order slab reduce)
+        L.check(L.lib().m3l_op_gemm_tn_grouped(1, cnt, M, L.ptr_array(Ys), Ns, L.ptr_array(Xs), Ks, Ns, Ks, L.ptr_array(outs), L.ptr(ws), nb, _s()),
+                "gemm_tn_grouped")
+        if rep == 0:
+            first = [o.clone() for o in outs]
+    for i in range(cnt):
+        ref = Ys[i].float().t() @ Xs[i].float()
+        assert (outs[i] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-4, (i, shapes[i])
+        assert torch.equal(outs[i], first[i]), i
+
+
 def _attn_ref(qkv, B, n, H):
     q, k, v = [t.reshape(B, n, H, 64).transpose(1, 2) for t in qkv.float().reshape(B, n, 3 * H * 64).chunk(3, dim=-1)]
     dots = (q @ k.transpose(-1, -2)) * 0.125

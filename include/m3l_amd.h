@@ -112,6 +112,8 @@ int m3l_set_t192(int on);
 /* height of the tall row tiles at width 192: 12 token tiles = 192 rows, one workgroup per CU, or 6 = 96 rows, 6 + 2 waves
  * and a 3-stage ring so that two workgroups share a CU and overlap each other's memory-only phases; env M3L_T192_TT.  Returns the previous value. */
 int m3l_set_t192_tt(int tt);
+/* experiment switch of the row-tiled feed-forward backward: phase-offset wave groups / static wave priority; 0, 0 = off */
+int m3l_set_t192_stagger(int lead_mask, int prio_mask);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.
  * Stable ascending argsort; outputs int64 (B, num_masked) / (B, num_unmasked) in the reference's concat order.
@@ -197,6 +199,11 @@ typedef struct m3l_mae_cfg {
     m3l_geom geom;
     m3l_tf_cfg enc, dec;
     double masking_ratio;
+    int early_conv;      /* early_conv_masking=True (train.py:62, the reference's default): EarlyCNN stems over the frames + visible gather
+                          * instead of the patch embed, loss over ALL patches (pretrain_models.py:180-191,311-322).  The embed group is then
+                          * 19 tensors: image stem {conv1.w, conv1.b, ..., conv4.w, conv4.b}, tactile stem (same 8), modality table, pos_img, pos_tac */
+    int learned_pos;     /* use_sincosmod_encodings=False (:218-219,280-287): the position tables are trained; their gradient slots (embed group
+                          * [13..14] / [17..18], glue group [4..5]) receive the batch sums of the token gradients */
 } m3l_mae_cfg;
 /* Data-parallel plan of m3l_mae_step_bwd (NULL = one rank): `flat` is the flat fp32 gradient buffer of `total` elements that the
  * grads pointers point into, laid out in backward order; stage_end[i] = end of the prefix of it that is final after stage i — stages:
@@ -218,6 +225,20 @@ int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const floa
 int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const float* const* tactiles, const int64_t* masked,
                      const int64_t* unmasked, const void* const* tensors, void* ws, const float* dloss, float* const* grads,
                      const m3l_comm_plan* comm, void* stream);
+
+/* ---- the policy-side consumer of the MAE in two calls: MAEExtractor.forward (models/pretrain_models.py:819-841; run on every environment
+ * step at B = number of envs, and with grad on every PPO minibatch, models/ppo_mae.py:280):
+ *     tokens = get_embeddings(x)  (encoder over ALL tokens, no masking, :588-668)  ->  `head` (the extractor's own 1-layer Transformer,
+ *     :807-817)  ->  mean over the tokens (:838)  ->  out (B, D) f32.
+ * c: geom (use_vision / use_tactile of the call = vision_only_control), enc, early_conv, learned_pos; dec and masking_ratio are unused.
+ * tensors / grads: front group (15, or 19 with early_conv) | encoder group (11 depth + 2) | head group (11 head->depth + 2).
+ * The workspace holds every activation between the two calls; m3l_extractor_fwd alone is the no-grad rollout path. */
+int m3l_extractor_num_tensors(const m3l_mae_cfg* c, const m3l_tf_cfg* head);
+size_t m3l_extractor_ws_bytes(const m3l_mae_cfg* c, const m3l_tf_cfg* head, int B);
+int m3l_extractor_fwd(const m3l_mae_cfg* c, const m3l_tf_cfg* head, int B, const float* image, const float* const* tactiles,
+                      const void* const* tensors, void* ws, float* out, void* stream);
+int m3l_extractor_bwd(const m3l_mae_cfg* c, const m3l_tf_cfg* head, int B, const float* image, const float* const* tactiles,
+                      const void* const* tensors, void* ws, const float* dout, float* const* grads, void* stream);
 
 /* ---- EarlyCNN stem (early_conv_masking=True, the reference's default flag; pretrain_models.py:37-56,180-191): three
  * Conv2d+ReLU and a 1x1 Conv2d as im2col + MFMA GEMM.  srcs: nsrc NCHW f32 inputs of B samples each (the tactile sensors share

@@ -29,7 +29,7 @@ class TfCfg(C.Structure):
 
 
 class MaeCfg(C.Structure):
-    _fields_ = [("geom", Geom), ("enc", TfCfg), ("dec", TfCfg), ("masking_ratio", C.c_double)]
+    _fields_ = [("geom", Geom), ("enc", TfCfg), ("dec", TfCfg), ("masking_ratio", C.c_double), ("early_conv", c_i), ("learned_pos", c_i)]
 
 
 class CommPlan(C.Structure):
@@ -48,6 +48,7 @@ _SIGS = {
     "m3l_set_direct_conv": (c_i, [c_i]),
     "m3l_set_t192": (c_i, [c_i]),
     "m3l_set_t192_tt": (c_i, [c_i]),
+    "m3l_set_t192_stagger": (c_i, [c_i, c_i]),
     "m3l_set_defer_join": (c_i, [c_i]),
     "m3l_set_wgrad_inline": (c_i, [c_i]),
     "m3l_side_join": (c_i, [c_p]),
@@ -87,6 +88,10 @@ _SIGS = {
     "m3l_mae_step_ws_bytes": (c_sz, [C.POINTER(MaeCfg), c_i]),
     "m3l_mae_step_fwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_mae_step_bwd": (c_i, [C.POINTER(MaeCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(CommPlan), c_p]),
+    "m3l_extractor_num_tensors": (c_i, [C.POINTER(MaeCfg), C.POINTER(TfCfg)]),
+    "m3l_extractor_ws_bytes": (c_sz, [C.POINTER(MaeCfg), C.POINTER(TfCfg), c_i]),
+    "m3l_extractor_fwd": (c_i, [C.POINTER(MaeCfg), C.POINTER(TfCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "m3l_extractor_bwd": (c_i, [C.POINTER(MaeCfg), C.POINTER(TfCfg), c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "m3l_earlycnn_ws_bytes": (c_sz, [C.POINTER(CnnCfg), c_i, c_i]),
     "m3l_earlycnn_fwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "m3l_earlycnn_bwd": (c_i, [C.POINTER(CnnCfg), c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

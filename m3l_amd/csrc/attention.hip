@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
                 s[t][r] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float mn = fmaxf(m, mx);
         const float alpha = __expf(m - mn);
         float ps = 0.f;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         }
         __syncthreads();
     }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = xor16_sum(lsum);
+    lsum = xor32_sum(lsum);
     if (q < n) {
         const float inv = 1.0f / lsum;
         T* orow = o + ((long)b * n + q) * ldo + hh * 64;
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart += to_f32(fdo[ks].v[j]) * to_f32(fo.v[j]);
     }
-    dpart += __shfl_xor(dpart, 16, 64);
-    dpart += __shfl_xor(dpart, 32, 64);
+    dpart = xor16_sum(dpart);
+    dpart = xor32_sum(dpart);
     const float Dq = dpart;
     const float lq = lse[((long)b * H + hh) * n + qc];
     if (q < n && g == 0) dsum[((long)b * H + hh) * n + q] = Dq;

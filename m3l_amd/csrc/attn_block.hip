@@ -249,8 +249,8 @@ __device__ M3L_BODY_INLINE void attn_block_fwd_body(
                         s[t][r] = v;
                         mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xor16_max(mx);
+                mx = xor32_max(mx);
                 const float mn = fmaxf(m, mx);
                 const float alpha = __expf(m - mn);
                 float ps = 0.f;
@@ -283,8 +283,8 @@ __device__ M3L_BODY_INLINE void attn_block_fwd_body(
                     oacc[d] = mma16(fv, fp, oacc[d]);
                 }
             }
-            lsum += __shfl_xor(lsum, 16, 64);
-            lsum += __shfl_xor(lsum, 32, 64);
+            lsum = xor16_sum(lsum);
+            lsum = xor32_sum(lsum);
             const float inv = 1.0f / lsum;
             // o (transposed accumulator: row = query li, columns 16 d + 4 g + r) -> LDS (XN region) and global
 #pragma unroll
@@ -811,9 +811,9 @@ __device__ M3L_BODY_INLINE void attn_block_bwd_body(
             f32x4 pg = dy[c] * xh[c], pb = dy[c], pc = rr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pg[e] += __shfl_xor(pg[e], 16, 64); pg[e] += __shfl_xor(pg[e], 32, 64);
-                pb[e] += __shfl_xor(pb[e], 16, 64); pb[e] += __shfl_xor(pb[e], 32, 64);
-                pc[e] += __shfl_xor(pc[e], 16, 64); pc[e] += __shfl_xor(pc[e], 32, 64);
+                pg[e] = xor16_sum(pg[e]); pg[e] = xor32_sum(pg[e]);
+                pb[e] = xor16_sum(pb[e]); pb[e] = xor32_sum(pb[e]);
+                pc[e] = xor16_sum(pc[e]); pc[e] = xor32_sum(pc[e]);
             }
             if (g == 0) {
                 *reinterpret_cast<f32x4*>(LP + (wave * 3 + 0) * D + col) = pg;

@@ -122,6 +122,33 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
     return v;
 }
+// Exchange between the lane groups of a wave (lanes i and i ^ 16, i and i ^ 32) by v_permlane16_swap / v_permlane32_swap (gfx950): two
+// VALU passes each instead of a ds_bpermute round trip through the LDS crossbar (~100+ cycles, and __shfl_xor(v, 16 / 32) compiles to
+// exactly that).  With both operands equal to v the swap leaves {v[i], v[i ^ 16]} (resp. 32) in the two registers, in an order that
+// depends on the lane: enough for commutative combinations, which is all the kernels need (LayerNorm / softmax sums and maxima over the
+// four 16-lane groups; every lane must be active).  Inline asm: the __builtin_amdgcn_permlane16_swap form is miscompiled by ROCm 7.2's
+// hipcc (both results come back as one register: tools/probes/permlane_swap_test.hip); s_nop 1 = the wait states a VALU write of the
+// operands needs in front of the swap.
+__device__ __forceinline__ float xor16_sum(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
 // sum over the whole wave (call with every lane active), every lane gets the total: the four row totals meet through v_readlane (scalar
 // registers) instead of a chain of six ds_bpermute round trips through the LDS crossbar (~500 cycles; the one-row-per-wave LayerNorm kernels
 // do two to four of these in a row and nothing hides them)

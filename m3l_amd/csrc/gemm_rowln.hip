@@ -30,8 +30,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // (row16_sum: common.cuh)
 // sum over the 4 lanes that hold the same row (same lane & 15)
 __device__ __forceinline__ float col4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = xor16_sum(v);
+    v = xor32_sum(v);
     return v;
 }
 

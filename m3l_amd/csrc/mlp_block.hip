@@ -403,8 +403,8 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
                 *reinterpret_cast<bf16*>(DS + off) = db_;
                 csum += (float)db_;
             }
-            csum += __shfl_xor(csum, 16, 64);
-            csum += __shfl_xor(csum, 32, 64);
+            csum = xor16_sum(csum);
+            csum = xor32_sum(csum);
             if (g == 0) CS[rt * mlp + 64 * c + 16 * ct + li] = csum;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -491,9 +491,9 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
             f32x4 pg = dy[c] * xh[c], pb = dy[c], pc = rr;                // sums over the wave's 4 rows (lanes that differ in g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pg[e] += __shfl_xor(pg[e], 16, 64); pg[e] += __shfl_xor(pg[e], 32, 64);
-                pb[e] += __shfl_xor(pb[e], 16, 64); pb[e] += __shfl_xor(pb[e], 32, 64);
-                pc[e] += __shfl_xor(pc[e], 16, 64); pc[e] += __shfl_xor(pc[e], 32, 64);
+                pg[e] = xor16_sum(pg[e]); pg[e] = xor32_sum(pg[e]);
+                pb[e] = xor16_sum(pb[e]); pb[e] = xor32_sum(pb[e]);
+                pc[e] = xor16_sum(pc[e]); pc[e] = xor32_sum(pc[e]);
             }
             if (g == 0) {
                 *reinterpret_cast<f32x4*>(LP + (wave * 3 + 0) * D + col) = pg;

@@ -85,8 +85,8 @@ __device__ __forceinline__ float row16_sum_t(float v) {   // sum over the 16 lan
 }
 // sum over the 4 lane groups (lanes li, li + 16, li + 32, li + 48): the reduction over a token's columns that sit in other lanes
 __device__ __forceinline__ float col4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = xor16_sum(v);
+    v = xor32_sum(v);
     return v;
 }
 
@@ -130,10 +130,10 @@ __device__ __forceinline__ void dma_f2_piece(const bf16* W, int ldw, int c0, int
 // the DMA waves' side of the ring: `nst` stages of CP chunks (PPW pieces per DMA wave), NSTAGE - 1 stages requested ahead.
 // issue(c, dst, p) loads piece p (0 .. PC - 1) of chunk c to the chunk image at dst.  One barrier per stage, matched by the compute waves;
 // `tail` extra barriers at the end.  Chunks past `nc` re-load the last chunk (same instruction count per stage: the counted waits hold).
-template <int D, int TT, int CP, typename Issue>
+template <int D, int TT, int CP, int LK = 0, typename Issue>
 __device__ __forceinline__ void dma_ring(int dw, int nc, char* ring, Issue issue, int tail) {
     using Cf = TileCfg<D, TT, CP>;
-    constexpr int LOOK = Cf::NSTAGE - 1;
+    constexpr int LOOK = LK > 0 ? LK : Cf::NSTAGE - 1;         // stages requested ahead (LK: the staggered kernel still reads stage s - 1 after barrier s)
     const int nst = (nc + CP - 1) / CP;
     auto stage = [&](int s) {
         char* dst = ring + (s % Cf::NSTAGE) * Cf::STAGE;
@@ -677,6 +677,128 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
 }
 
+// ---- experiment: the same kernel with the second product of a chunk deferred by one ring stage, in two phase
+// orders.  Between two stage barriers a wave runs   [P3' = yacc += W1^T(prev chunk) du(prev)]  [P1 = t = W2^T dx]  [P2 = du = t gelu'(u),
+// store, column sums]   — P3' FIRST for the waves of `lead_mask` (MFMA, MFMA, VALU), LAST for the others (MFMA, VALU, MFMA): SIMD
+// partners then meet in different phases (one's GELU' / du store beside the other's MFMAs) instead of all waves reaching the matrix
+// pipe, the VALU and the barrier together.  du of the previous chunk is carried in 4 registers; the DMA waves run one stage less
+// ahead (stage s - 1 is still read after barrier s).  <192, 12, 1> only.  prio_mask: static s_setprio 1 for those waves.
+template <int D, int TT, int CP>
+__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_bwd_stg_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
+                                                                   const float* __restrict__ x1, const float* __restrict__ ln2_w,
+                                                                   const bf16* __restrict__ u, const bf16* __restrict__ W2T,
+                                                                   const bf16* __restrict__ W1T, float eps, int M, int mlp,
+                                                                   bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
+                                                                   float* __restrict__ cs_part, float* __restrict__ ln_part, int lead_mask, int prio_mask) {
+    using Cf = TileCfg<D, TT, CP>;
+    using Lay = MlpBwdLayout<D, TT, CP>;
+    static_assert(CP == 1 && Cf::NSTAGE >= 4 && Lay::CS_LDS, "staggered variant: one parity, four ring stages");
+    constexpr int NCW = Cf::NCW, KS = Cf::KS, ND = Cf::ND;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem + Lay::RING;
+    float* CS = reinterpret_cast<float*>(smem + Lay::CS);
+    float* G = CS + TT * mlp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const long row0 = (long)blockIdx.x * Cf::ROWS;
+    const int NC = mlp >> 5;
+
+    if (wave >= NCW) {
+        dma_ring<D, TT, CP, Cf::NSTAGE - 2>(wave - NCW, NC, RING, [&](int c, char* dst, int p) {
+            if (p < Cf::PCB) dma_f1_piece(W2T, D, 32 * c, p, dst, lane);
+            else dma_f2_piece(W1T, mlp, 32 * c, p - Cf::PCB, dst + Cf::BLK, lane);
+        }, 3);
+        return;
+    }
+    const bool lead = (lead_mask >> wave) & 1;                // wave-uniform
+    if ((prio_mask >> wave) & 1) __builtin_amdgcn_s_setprio(1);
+    const long trow = row0 + 16 * wave + li;
+    const bool ok = trow < M;
+    Frag<bf16> db[KS];
+    load_tok_frags(dxt, ok ? trow : (long)M - 1, ok, g, db);
+    for (int id = tid; id < D; id += 64 * NCW) G[id] = ln2_w[id];
+    float* CSw = CS + wave * mlp;
+    f32x4 yacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 un = uint4{0u, 0u, 0u, 0u};
+    if (ok) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 8 * g);
+    Frag<bf16> dprev;
+    dprev.v = __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u});
+    // second product of the previous chunk: F2 block of stage (st - 1); with dprev = 0 at st = 0 it adds nothing (the block then holds
+    // whatever the ring held: finite or not, 0 * x ... so it is skipped at st = 0 instead)
+    auto p3 = [&](const char* Wp) {
+        Frag<bf16> f0 = frag_f2(Wp, 0, li, g), f1 = frag_f2(Wp, 1, li, g);
+#pragma unroll
+        for (int d2 = 0; d2 < KS; ++d2) {
+            const Frag<bf16> a0 = f0, a1 = f1;
+            asm volatile("" ::: "memory");
+            if (d2 + 1 < KS) { f0 = frag_f2(Wp, 2 * d2 + 2, li, g); f1 = frag_f2(Wp, 2 * d2 + 3, li, g); }
+            asm volatile("" ::: "memory");
+            yacc[2 * d2] = mma16(a0, dprev, yacc[2 * d2]);
+            yacc[2 * d2 + 1] = mma16(a1, dprev, yacc[2 * d2 + 1]);
+        }
+    };
+    for (int st = 0; st < NC; ++st) {
+        __builtin_amdgcn_s_barrier();                         // stage st landed
+        asm volatile("" ::: "memory");
+        const Frag<bf16> uc = {__builtin_bit_cast(bf16x8, un)};
+        if (ok && st + 1 < NC) un = *reinterpret_cast<const uint4*>(u + trow * mlp + 32 * (st + 1) + 8 * g);
+        const char* Wa = RING + (st % Cf::NSTAGE) * Cf::STAGE;
+        const char* Wp = RING + ((st + Cf::NSTAGE - 1) % Cf::NSTAGE) * Cf::STAGE + Cf::BLK;
+        if (lead && st > 0) p3(Wp);
+        f32x4 ta[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        {
+            Frag<bf16> f0 = frag_f1p(Wa, 0, 0, li, g), f1 = frag_f1p(Wa, 1, 0, li, g);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const Frag<bf16> a0 = f0, a1 = f1;
+                asm volatile("" ::: "memory");
+                if (ks + 1 < KS) { f0 = frag_f1p(Wa, 0, ks + 1, li, g); f1 = frag_f1p(Wa, 1, ks + 1, li, g); }
+                asm volatile("" ::: "memory");
+                ta[0] = mma16(a0, db[ks], ta[0]);
+                ta[1] = mma16(a1, db[ks], ta[1]);
+            }
+        }
+        Frag<bf16> dub;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = j < 4 ? ta[0][j & 3] : ta[1][j & 3];
+            dub.v[j] = (bf16)(t * gelu_grad_fast((float)uc.v[j]));
+        }
+        if (ok) *reinterpret_cast<bf16x8*>(du_out + trow * mlp + 32 * st + 8 * g) = dub.v;
+        {
+            float cs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] = row16_sum_t(ok ? (float)dub.v[j] : 0.f);
+            if (li == 0) {
+                *reinterpret_cast<f32x4*>(CSw + 32 * st + 8 * g) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                *reinterpret_cast<f32x4*>(CSw + 32 * st + 8 * g + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+            }
+        }
+        if (!lead && st > 0) p3(Wp);
+        dprev = dub;
+    }
+    p3(RING + ((NC - 1) % Cf::NSTAGE) * Cf::STAGE + Cf::BLK);     // the last chunk's second product (the ring is no longer overwritten)
+    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);
+    {
+        const float* LP0 = reinterpret_cast<const float*>(RING);
+        for (int id = tid; id < 3 * D; id += 64 * NCW) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < TT; ++w) a += LP0[w * 3 * D + id];
+            ln_part[(long)blockIdx.x * 3 * D + id] = a;
+        }
+        for (int id = tid; id < mlp; id += 64 * NCW) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < TT; ++w) a += CS[w * mlp + id];
+            cs_part[(long)blockIdx.x * mlp + id] = a;
+        }
+    }
+    __builtin_amdgcn_s_barrier();                             // T3 (matches the DMA waves' tail count)
+}
+
 // =============================================================================================================================
 // Attention half, last step of the backward:   dxn1 = dqkv Wqkv  (k = 3 H 64);   dx = dres + LN1-backward(dxn1; x, gamma1)
 // (+ compute-type copy for the next layer's weight gradients, + [3 D] partials dgamma1 | dbeta1 | colsum dx = fc2 bias gradient of
@@ -910,8 +1032,8 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_ke
                 sc[t][r] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 12; ++t)
@@ -1214,6 +1336,23 @@ extern "C" int m3l_set_t192_tt(int tt) {
     g_tall_tt = tt == 6 ? 6 : 12;
     return old;
 }
+// experiment knobs of mlp_t192_bwd: lead_mask = compute waves that run a chunk's deferred second product FIRST in the
+// staggered kernel (bit 12 set = use the staggered kernel even with an empty mask), prio_mask = waves that raise their priority.
+// env M3L_T192_STG / M3L_T192_PRIO, or m3l_set_t192_stagger (returns the previous lead mask).
+static int g_stg = -1, g_prio = 0;
+static void stg_init() {
+    if (g_stg < 0) {
+        g_stg = getenv("M3L_T192_STG") ? (int)strtol(getenv("M3L_T192_STG"), nullptr, 0) : 0;
+        g_prio = getenv("M3L_T192_PRIO") ? (int)strtol(getenv("M3L_T192_PRIO"), nullptr, 0) : 0;
+    }
+}
+extern "C" int m3l_set_t192_stagger(int lead_mask, int prio_mask) {
+    stg_init();
+    const int old = g_stg;
+    g_stg = lead_mask & 0x1fff;
+    g_prio = prio_mask & 0xfff;
+    return old;
+}
 static int t192_tt(int M) { return (cdiv(M, 192) >= t192_min_tiles() || forced()) ? tall_tt() : 3; }   // bit 4: tall tiles at any M (tests)
 static int tile_rows(int D, int M) { return D == 192 ? 16 * t192_tt(M) : 16 * (D == 256 ? WideTile<256>::TT : WideTile<384>::TT); }
 int m3l_mlp_t192_tiles(int D, int M) { return cdiv(M, tile_rows(D, M)); }
@@ -1293,6 +1432,20 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
     T192_DISPATCH(Dm, tt, {
         LDS_ONCE((mlp_t192_bwd_kernel<D, TT, CP>), (MlpBwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
         M3L_CHECK((MlpBwdLayout<D, TT, CP>::total(mlp)) <= (size_t)160 * 1024, "mlp_t192_bwd: %zu bytes of LDS", (MlpBwdLayout<D, TT, CP>::total(mlp)));
+        // experiment knobs: M3L_T192_STG = mask of the compute waves that run the deferred product FIRST (0x1000 = staggered kernel, none lead),
+        // M3L_T192_PRIO = mask of the waves that raise their priority
+        stg_init();
+        const int stg = g_stg, prio = g_prio;
+        if constexpr (D == 192 && TT == 12 && CP == 1 && T192_NS_TALL == 4) {
+            if (stg || prio) {
+                LDS_ONCE((mlp_t192_bwd_stg_kernel<D, TT, CP>), (MlpBwdLayout<D, TT, CP>::total(1024)));
+                mlp_t192_bwd_stg_kernel<D, TT, CP><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
+                    (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t, cs_part,
+                    ln_part, stg & 0xfff, prio);
+                M3L_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         mlp_t192_bwd_kernel<D, TT, CP><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
             (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t, cs_part,
             ln_part);

@@ -95,7 +95,7 @@ def _grad_targets(sink, params, used=None):
     if direct:
         sync = sink[0]
         ids = [id(p) for i, p in enumerate(params)
-               if p is not None and (used is None or used[i]) and getattr(p, "grad", None) is not None and p.requires_grad]
+               if p is not None and (used is None or used[i]) and p.is_leaf and p.grad is not None and p.requires_grad]
         if any(i in sync._written for i in ids):
             if sync._comm:
                 raise RuntimeError("GradSync: second backward through the same parameters before zero_grad() while gradients are being "
@@ -113,7 +113,7 @@ def _grad_targets(sink, params, used=None):
         ok = p is not None and (used is None or used[i])
         if not ok:
             out.append(None)
-        elif direct and getattr(p, "grad", None) is not None and p.requires_grad:
+        elif direct and p.is_leaf and p.grad is not None and p.requires_grad:
             out.append(p.grad)
         else:
             out.append(torch.zeros_like(p))
@@ -408,16 +408,16 @@ class StepPlan:
     """Everything one fused step needs, assembled by VTMAE._step_fused: cfg (L.MaeCfg), the five tensor groups as one list, which of
     them take a gradient in this call, the inputs and the GradSync (or None)."""
     __slots__ = ("cfg", "tensors", "used", "image", "tactiles", "noises", "sync", "B", "nmask", "nvis", "ws", "keep", "versions", "tens_arr",
-                 "tac_arr", "masked", "unmasked")
+                 "tac_arr", "masked", "unmasked", "extra", "head_cfg")
 
 
 def _comm_plan(sync, plan, cfg):
     """m3l_comm_plan for this model on `sync` (cached: the layout never changes): stage ends in the flat gradient buffer."""
-    key = (cfg.enc.depth, cfg.dec.depth, sync.layers_per_chunk, sync.min_bucket_elems)
+    key = (cfg.enc.depth, cfg.dec.depth, sync.layers_per_chunk, sync.min_bucket_elems, cfg.early_conv, cfg.learned_pos)
     cached = getattr(sync, "_step_plan", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    groups = [15, 11 * cfg.enc.depth + 2, 6, 11 * cfg.dec.depth + 2, 4]
+    groups = [19 if cfg.early_conv else 15, 11 * cfg.enc.depth + 2, 6, 11 * cfg.dec.depth + 2, 4]
     off = [0]
     for n in groups:
         off.append(off[-1] + n)
@@ -443,7 +443,8 @@ def _comm_plan(sync, plan, cfg):
     for i, e in enumerate(ends):          # a stage with no parameters of its own (Identity enc_to_dec ...) keeps the previous prefix
         run = max(run, e)
         ends[i] = run
-    ends[-1] = sync.flat.numel()          # whatever is left (nothing, in the layouts GradSync builds) goes with the last stage
+    if not cfg.learned_pos:               # whatever is left (nothing, in the layouts GradSync builds) goes with the last stage; learned position
+        ends[-1] = sync.flat.numel()      # tables own the trailing span, final only after autograd has accumulated them: finish() sends it
     arr = (C.c_long * len(ends))(*ends)
     sent = C.c_long(0)
     cp = L.CommPlan(sync.flat.data_ptr(), sync.flat.numel(), sync.min_bucket_elems, int(sync.layers_per_chunk or 0), len(ends), arr, C.pointer(sent))
@@ -474,6 +475,7 @@ class MaeStepFn(torch.autograd.Function):
         plan.noises = None
         ctx.plan = plan
         ctx.n_in = len(tensors)
+        ctx.anchor_mode = plan.extra is not None
         return loss
 
     @staticmethod
@@ -502,18 +504,21 @@ class MaeStepFn(torch.autograd.Function):
         finally:
             if defer:
                 lib.m3l_set_defer_join(0)
+        # anchor mode: autograd sees the anchor parameter and the tensors whose gradient must travel through autograd (`plan.extra`: the
+        # slices of the learned position tables — non-leaf views, their gradient reaches the parameter through the slice's backward)
+        extras = tuple(grads[i] for i in plan.extra) if ctx.anchor_mode else ()
         if direct:
             sync._reduced.update(sync._bucket_ids)
             if comm is not None:
                 sync._sent_end = int(comm[2].value)
                 sync._unscaled = True
-            return (None,) * (1 + ctx.n_in)
-        if sync is not None and ctx.n_in == 1:
+            return (None, None) + extras
+        if ctx.anchor_mode:
             # anchor mode, second backward before zero_grad() (gradient accumulation / the reference's separate_optimizer=False update):
             # autograd sees one input, so the fresh gradients are added into the flat views here (_grad_targets has joined the side stream)
             dst, src = [], []
-            for g, t in zip(grads, plan.tensors):
-                if g is None or t is None or not t.requires_grad:
+            for i, (g, t) in enumerate(zip(grads, plan.tensors)):
+                if g is None or t is None or not t.requires_grad or i in plan.extra:
                     continue
                 if t.grad is None:
                     t.grad = g
@@ -522,8 +527,46 @@ class MaeStepFn(torch.autograd.Function):
                     src.append(g)
             if dst:
                 torch._foreach_add_(dst, src)
-            return (None,) * (1 + ctx.n_in)
+            return (None, None) + extras
         return (None,) + tuple(g for g, t in zip(grads, plan.tensors) if t is not None)      # the autograd inputs = the non-None tensors
+
+
+FUSED_EXTRACTOR = True     # tests switch it off to compare against the per-module path
+
+
+class ExtractorFn(torch.autograd.Function):
+    """MAEExtractor.forward (models/pretrain_models.py:819-841) after vt_load — get_embeddings over all tokens -> the extractor's 1-layer
+    Transformer -> mean over tokens — through m3l_extractor_fwd / m3l_extractor_bwd: one autograd node, two host calls (one under
+    no_grad: the rollout path at B = number of envs).  `tensors`: every tensor of the chain (front | encoder | head groups); gradients
+    go back through autograd (they accumulate: the policy loss reaches the MAE after the MAE loss, ppo_mae.py:249-280)."""
+
+    @staticmethod
+    def forward(ctx, plan, *tensors):
+        lib = L.lib()
+        dev = plan.image.device if plan.image is not None else plan.tactiles[0].device
+        plan.keep = []
+        plan.ws = _ws(lib.m3l_extractor_ws_bytes(C.byref(plan.cfg), C.byref(plan.head_cfg), plan.B), dev)
+        out = torch.empty(plan.B, plan.cfg.enc.dim, dtype=torch.float32, device=dev)
+        plan.tens_arr = _dev_ptrs(plan.tensors, plan.keep)
+        plan.tac_arr = L.ptr_array(plan.tactiles)
+        L.check(lib.m3l_extractor_fwd(C.byref(plan.cfg), C.byref(plan.head_cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws),
+                                      L.ptr(out), _stream()), "m3l_extractor_fwd")
+        plan.versions = _versions(plan.tensors)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        for i, (t, v) in enumerate(zip(plan.tensors, plan.versions)):
+            if t is not None and t._version != v:
+                raise RuntimeError(f"ExtractorFn: parameter {i} was modified by an inplace operation between forward and backward "
+                                   f"(version {t._version}, expected {v})")
+        grads = [torch.zeros_like(t) if (t is not None and u) else None for t, u in zip(plan.tensors, plan.used)]
+        dout = _f32c(dout)
+        L.check(L.lib().m3l_extractor_bwd(C.byref(plan.cfg), C.byref(plan.head_cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws),
+                                          L.ptr(dout), L.ptr_array(grads), _stream()), "m3l_extractor_bwd")
+        return (None,) + tuple(g for g, t in zip(grads, plan.tensors) if t is not None)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -20,9 +20,40 @@ Reference defect NOT reproduced: the middle-frame slice `image[:, 3*mid-3 : 3*mi
 import torch
 import torch.nn as nn
 
+from . import _lib as L
 from . import functional as Fn
 from .pretrain_models import VTT
 from .pretrain_utils import vt_load
+
+
+def pooled_embeddings(mae, head, vt, use_tactile=True):
+    """torch.mean(head(mae.get_embeddings(vt, eval=False, use_tactile=...)), dim=1) — the chain both reference extractors run
+    (models/pretrain_models.py:834-838, models/pretrain_models_dino_cat_mae.py:887-896) — as ONE autograd node over m3l_extractor_fwd /
+    m3l_extractor_bwd (csrc/mae_step.hip) when the library chain applies, else through the per-module Functions.  head: a Transformer."""
+    mae.train()                                               # get_embeddings(eval=False) leaves the MAE in train mode (:590-593)
+    image, tactiles, geom, ref = mae._inputs(vt, True, use_tactile)
+    enc_tf = mae.encoder.transformer
+    fused = (Fn.FUSED_EXTRACTOR and head.dim == enc_tf.dim and head.compute_dtype == enc_tf.compute_dtype
+             and (not mae.early_conv_masking or (mae.encoder.image_patch_height == 8 and mae.encoder.tactile_patch_height == 4)))
+    if not fused:
+        tokens = mae.get_embeddings(vt, eval=False, use_tactile=use_tactile)
+        return torch.mean(head(tokens), dim=1)
+    Fn._require_cuda(ref, "MAE input")
+    plan = Fn.StepPlan()
+    learned = not mae.use_sincosmod_encodings
+    plan.cfg = L.MaeCfg(geom, enc_tf._cfg(), enc_tf._cfg(), 0.5, int(mae.early_conv_masking), int(learned))
+    plan.head_cfg = head._cfg()
+    has_img, has_tac = image is not None, len(tactiles) > 0
+    front, used = mae._front_tensors(geom, has_img, has_tac)
+    plan.tensors = front + enc_tf._tensors() + head._tensors()
+    plan.used = used + [True] * (11 * enc_tf.depth + 2) + [True] * (11 * head.depth + 2)
+    for i, t in enumerate(plan.tensors):
+        if t is None:
+            plan.used[i] = False
+    plan.image = Fn._f32c(image)
+    plan.tactiles = [Fn._f32c(t) for t in tactiles]
+    plan.B = ref.shape[0]
+    return Fn.ExtractorFn.apply(plan, *[t for t in plan.tensors if t is not None])
 
 
 def _flatten_frame_stack(observations):
@@ -56,8 +87,7 @@ class MAEExtractor(nn.Module):
     def forward(self, observations):
         dev = self.vit_layer.pos_embedding.device
         vt = vt_load(_flatten_frame_stack(observations), frame_stack=self.frame_stack, device=dev)
-        tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
-        return self.flatten(torch.mean(self.vit_layer.transformer(tokens), dim=1))
+        return self.flatten(pooled_embeddings(self.mae_model, self.vit_layer.transformer, vt, use_tactile=not self.vision_only_control))
 
 
 class DinoCatMAEExtractor(nn.Module):
@@ -89,9 +119,8 @@ class DinoCatMAEExtractor(nn.Module):
     def forward(self, observations):
         dev = self.query.device
         vt = vt_load(_flatten_frame_stack(observations), frame_stack=self.frame_stack, device=dev)
-        tokens = self.mae_model.get_embeddings(vt, eval=False, use_tactile=not self.vision_only_control)
+        pooled = pooled_embeddings(self.mae_model, self.vit_layer.transformer, vt, use_tactile=not self.vision_only_control)
         dino = self.dino_model(self.middle_frame(vt["image"]))
-        pooled = torch.mean(self.vit_layer.transformer(tokens), dim=1)
         return self.run_mlp(Fn.Concat2Fn.apply(self.flatten(pooled), dino))
 
     def run_mlp(self, x):

@@ -311,16 +311,26 @@ class VTMAE(nn.Module):
                                 *self._embed_tensors(geom))
 
     # ------------------------------------------------------------------------------------------------------------
+    def _front_tensors(self, geom, has_img, has_tac):
+        """(tensors, used) of the encoder's front end in the order the C step expects: patch embed (15) or EarlyCNN stems (8 + 8 + 3)."""
+        learned = not self.use_sincosmod_encodings
+        if self.early_conv_masking:
+            t = self.early_conv_vision._tensors() + self.early_conv_tactile._tensors() + list(self._enc_positions(geom))
+            return t, [has_img] * 8 + [has_tac] * 8 + [True, learned and has_img, learned and has_tac]
+        return self._embed_tensors(geom), [has_img] * 6 + [has_tac] * 6 + [True, learned and has_img, learned and has_tac]
+
     def _step_fused(self, image, tactiles, geom, mask_noise, c, B, sync):
         """The whole step inside the library (csrc/mae_step.hip: m3l_mae_step_fwd / _bwd): one autograd node, two host calls."""
         plan = Fn.StepPlan()
         enc_tf, dec_tf = self.encoder.transformer, self.decoder
-        plan.cfg = L.MaeCfg(geom, enc_tf._cfg(), dec_tf._cfg(), float(self.masking_ratio))
-        emb, glue = self._embed_tensors(geom), self._glue_tensors(geom)
-        plan.tensors = emb + enc_tf._tensors() + glue + dec_tf._tensors() + self._head_tensors()
+        learned = not self.use_sincosmod_encodings
+        plan.cfg = L.MaeCfg(geom, enc_tf._cfg(), dec_tf._cfg(), float(self.masking_ratio), int(self.early_conv_masking), int(learned))
         has_img, has_tac = image is not None, len(tactiles) > 0
-        # which tensors receive a gradient in this call (absent modalities and the fixed sincos tables do not)
-        plan.used = ([has_img] * 6 + [has_tac] * 6 + [True, False, False] + [True] * (11 * enc_tf.depth + 2) + [True, True, True, True, False, False]
+        emb, used_emb = self._front_tensors(geom, has_img, has_tac)
+        glue = self._glue_tensors(geom)
+        plan.tensors = emb + enc_tf._tensors() + glue + dec_tf._tensors() + self._head_tensors()
+        # which tensors receive a gradient in this call (absent modalities and the fixed sincos tables do not; learned position tables do)
+        plan.used = (used_emb + [True] * (11 * enc_tf.depth + 2) + [True, True, True, True, learned and has_img, learned and has_tac]
                      + [True] * (11 * dec_tf.depth + 2) + [has_img] * 2 + [has_tac] * 2)
         for i, t in enumerate(plan.tensors):
             if t is None:
@@ -329,14 +339,15 @@ class VTMAE(nn.Module):
         plan.tactiles = [Fn._f32c(t) for t in tactiles]
         plan.noises = [Fn._f32c(n) for n in mask_noise]
         plan.sync, plan.B, plan.nmask, plan.nvis = sync, B, c["num_masked"], c["num_unmasked"]
-        anchor = next((t for t in plan.tensors if t is not None and t.requires_grad), None)
+        anchor = next((t for t in plan.tensors if t is not None and t.requires_grad and t.is_leaf), None)
         if sync is not None and torch.is_grad_enabled() and anchor is not None:
-            ins = (anchor,)                   # anchor: the kernels write every gradient in place, autograd only has to call backward
+            # anchor: the kernels write every gradient in place, autograd only has to call backward — and to carry the gradients of the
+            # learned position slices (views of encoder.pos_embedding / decoder_pos_emb.weight) back to their parameters
+            plan.extra = [i for i, t in enumerate(plan.tensors) if t is not None and plan.used[i] and t.requires_grad and not t.is_leaf]
+            ins = (anchor,) + tuple(plan.tensors[i] for i in plan.extra)
         else:
+            plan.extra = None
             ins = tuple(t for t in plan.tensors if t is not None)
-            for i, t in enumerate(plan.tensors):
-                if t is None:
-                    plan.used[i] = False
         loss = Fn.MaeStepFn.apply(plan, *ins)
         self.last_mask = (plan.masked, plan.unmasked)
         return loss
@@ -352,8 +363,8 @@ class VTMAE(nn.Module):
             mask_noise = [torch.rand(B, n, device=dev) for n in sizes]          # reference RNG order (:229,:237)
         assert [tuple(n.shape) for n in mask_noise] == [(B, n) for n in sizes], "mask_noise: one (B, n) tensor per modality"
         sync = self._sinks["heads"][0] if "heads" in self._sinks else None
-        if (Fn.FUSED_STEP and dump is None and counts is None and not self.early_conv_masking and self.use_sincosmod_encodings
-                and Fn.BWD_CHUNK_LAYERS is None and (sync is None or not sync._comm or sync._direct)):
+        if (Fn.FUSED_STEP and dump is None and counts is None and Fn.BWD_CHUNK_LAYERS is None and (sync is None or not sync._comm or sync._direct)
+                and (not self.early_conv_masking or (self.encoder.image_patch_height == 8 and self.encoder.tactile_patch_height == 4))):
             return self._step_fused(image, tactiles, geom, [n.to(dev) for n in mask_noise], c, B, sync)
         masked, unmasked, c = Fn.mask_sample(geom, self.masking_ratio, [n.to(dev) for n in mask_noise], counts)
         self.last_mask = (masked, unmasked)

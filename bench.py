@@ -137,21 +137,62 @@ def secondary_workloads(dtype, dev, names=("cfg4", "cfg5", "ref"), steps=10, war
         # three windows of `steps` steps, the median one reported: a single host / allocator hiccup of a few tens of ms inside a 20-60 ms
         # window otherwise halves a figure (seen once in a while on the pool's boxes; the headline measurement keeps the contract's
         # single K-step window)
-        els = []
+        els, enq = [], []
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 loss = step()
+            enq.append(time.perf_counter() - t0)
             torch.cuda.synchronize()
             els.append(time.perf_counter() - t0)
         el = sorted(els)[1]
         rows[name] = {"workload": desc, "batch": B, "steps": steps, "windows": 3, "ms_per_step": round(el / steps * 1e3, 3),
                       "samples_per_s": round(B * steps / el, 1), "model_tflops": round(3 * fwd_flops_per_sample(c) * B * steps / el / 1e12, 1),
-                      "loss": round(float(loss.detach()), 5)}
+                      "host_enqueue_ms_per_step": round(sorted(enq)[1] / steps * 1e3, 3), "loss": round(float(loss.detach()), 5)}
+        if name == "ref":
+            rows.update(extractor_rows(mae, c, dev, steps, warmup))
         del mae, sync, opt, x
         torch.cuda.empty_cache()
     return rows
+
+
+def extractor_rows(mae, c, dev, steps, warmup):
+    """the policy-side consumer of the MAE, `MAEExtractor.forward` (models/pretrain_models.py:819-841) on M3L's default
+    architecture — observations -> vt_load -> get_embeddings over all tokens -> the extractor's 1-layer Transformer -> mean — as the
+    reference calls it: on every environment step at B = 8 under no_grad (a latency figure: obs/s and ms per call) and on every PPO
+    minibatch at B = 512 with grad (models/ppo_mae.py:280; forward + backward, samples/s).  Both through m3l_extractor_fwd / _bwd."""
+    from m3l_amd import MAEExtractor
+    fs = c.get("frame_stack", 1)
+    ext = MAEExtractor(mae, c["dim"], False, fs).to(dev)
+    out = {}
+    for tag, B, grad in (("extractor_rollout_B8", 8, False), ("extractor_train_B512", 512, True)):
+        obs = {"image": torch.rand(B, fs, c["image_size"], c["image_size"], 3, device=dev),
+               "tactile": torch.rand(B, fs, 3 * c["num_tactiles"], c["tactile_size"], c["tactile_size"], device=dev) * 2 - 1}
+
+        def call():
+            if not grad:
+                with torch.no_grad():
+                    return ext(obs)
+            ext.zero_grad(set_to_none=True)
+            f = ext(obs)
+            f.square().mean().backward()
+            return f
+        for _ in range(warmup):
+            call()
+        els = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
+        out[tag] = {"workload": ("MAEExtractor.forward under no_grad (rollout)" if not grad else "MAEExtractor forward + backward (PPO minibatch)") +
+                                " on the M3L default architecture, vt_load included", "batch": B, "steps": steps, "windows": 3,
+                    "ms_per_call": round(el / steps * 1e3, 3), "obs_per_s": round(B * steps / el, 1)}
+    return out
 
 
 CFG1 = dict(CFG2, num_tactiles=0)     # BASELINE configs[0]: vision-only MAE, 64x64 RGB, ViT-Tiny, mask 75 %, batch 8 on CPU

@@ -83,6 +83,7 @@ class MAEExtractor(nn.Module):
         self.frame_stack = frame_stack
         self.vit_layer = VTT(image_size=(64, 64), tactile_size=(32, 32), image_patch_size=8, tactile_patch_size=4,    # sizes unused:
                              dim=dim_embeddings, depth=1, heads=4, mlp_dim=dim_embeddings * 2, num_tactiles=2)       # only .transformer runs
+        self.vit_layer.transformer.compute_dtype = getattr(mae_model, "compute_dtype", "fp32")     # one compute type for the whole chain
 
     def forward(self, observations):
         dev = self.vit_layer.pos_embedding.device
@@ -103,6 +104,7 @@ class DinoCatMAEExtractor(nn.Module):
         self.frame_stack = frame_stack
         self.vit_layer = VTT(image_size=(70, 70), tactile_size=(70, 70), image_patch_size=14, tactile_patch_size=14,   # sizes unused:
                              dim=dim_embeddings, depth=1, heads=4, mlp_dim=dim_embeddings * 2, num_tactiles=2)        # only .transformer runs
+        self.vit_layer.transformer.compute_dtype = getattr(mae_model, "compute_dtype", "fp32")      # one compute type for the whole chain
         self.mlp = nn.Sequential(nn.Linear(dim_embeddings * 2, dim_embeddings * 2), nn.ReLU(), nn.Dropout(0.1),
                                  nn.Linear(dim_embeddings * 2, dim_embeddings * 2), nn.ReLU(), nn.Dropout(0.1),
                                  nn.Linear(dim_embeddings * 2, dim_embeddings))

@@ -251,11 +251,14 @@ def test_direct_grad_mode_matches_autograd_mode(sincos):
 
 
 @pytest.mark.parametrize("with_sync", [False, True])
-@pytest.mark.parametrize("arch", ["tiny_bf16", "decdim_bf16", "vision_only_fp32", "tiny_fp32"])
+@pytest.mark.parametrize("arch", ["tiny_bf16", "decdim_bf16", "vision_only_fp32", "tiny_fp32", "earlyconv_bf16", "earlyconv_fp32", "learnedpos_fp32",
+                                  "earlyconv_learnedpos_bf16"])
 def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
     """csrc/mae_step.hip: the whole step as two library calls (one autograd node) against the five per-module autograd Functions —
     same kernels in the same order, so loss, mask indices and every parameter gradient must be bit-identical; with a GradSync (the
-    kernels write the flat buffer, autograd sees one anchor input) and without (autograd receives every gradient)."""
+    kernels write the flat buffer, autograd sees one anchor input) and without (autograd receives every gradient).  Round 4: the
+    EarlyCNN front end with its all-patch loss (early_conv_masking=True, the reference's default, train.py:62) and learned position
+    tables (use_sincosmod_encodings=False: their gradients reach the parameters through autograd in both modes)."""
     from m3l_amd import functional as Fn
     from m3l_amd.parallel import GradSync
     kw = dict(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=128, depth=3, heads=2, mlp_dim=256)
@@ -265,6 +268,10 @@ def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
     if arch == "vision_only_fp32":
         kw.update(num_tactiles=0)
         mkw.update(num_tactiles=0)
+    if "earlyconv" in arch:
+        mkw.update(early_conv_masking=True)
+    if "learnedpos" in arch:
+        mkw.update(use_sincosmod_encodings=False)
     dt = "fp32" if arch.endswith("fp32") else "bf16"
     B = 6
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -296,10 +303,16 @@ def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
     l0, m0, g0 = run(False)
     l1, m1, g1 = run(True)
     assert torch.equal(l0, l1) and torch.equal(m0[0], m1[0]) and torch.equal(m0[1], m1[1])
-    for n in g0:
+    pos_tables = ("encoder.pos_embedding", "decoder_pos_emb.weight")      # batch sums: torch.sum in the module chain, the library's fixed-order
+    for n in g0:                                                          # reduction in the fused step -> equal to fp32 round-off, not bit for bit
         assert (g0[n] is None) == (g1[n] is None), n
-        if g0[n] is not None:
+        if g0[n] is not None and n in pos_tables:
+            assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * float(g0[n].abs().max()) + 1e-9, n
+        elif g0[n] is not None:
             assert torch.equal(g0[n], g1[n]), n
+    if "learnedpos" in arch:
+        assert g1["encoder.pos_embedding"] is not None and g1["decoder_pos_emb.weight"] is not None
+        assert float(g1["encoder.pos_embedding"][0, 1:].abs().max()) > 0 and float(g1["decoder_pos_emb.weight"].abs().max()) > 0
     # use_vision / use_tactile flags go through the fused step too
     if nt:
         torch.manual_seed(2)
@@ -318,7 +331,10 @@ def test_fused_step_is_bit_identical_to_module_chain(arch, with_sync):
         for n in res[0][1]:
             a, b = res[0][1][n], res[1][1][n]
             assert (a is None) == (b is None), n
-            assert a is None or torch.equal(a, b), n
+            if a is not None and n in pos_tables:
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, n
+            else:
+                assert a is None or torch.equal(a, b), n
 
 
 @pytest.mark.parametrize("t192_mode", [1, 7])
@@ -1085,6 +1101,53 @@ def test_mae_extractor_golden(golden_dir, tag):
                     ("vit_layer.transformer.layers.0.1.net.1.weight", ext.vit_layer.transformer.layers[0][1].net[1].weight)):
         ref = z[f"{tag}/grad/{name}"]
         assert np.abs(p.grad.cpu().numpy() - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-7, name
+
+
+@pytest.mark.parametrize("arch", ["patch_fp32", "patch_bf16", "earlyconv_bf16", "vision_only_control_fp32"])
+def test_fused_extractor_is_bit_identical_to_module_chain(arch):
+    """m3l_extractor_fwd / m3l_extractor_bwd (MAEExtractor.forward, models/pretrain_models.py:819-841, as one autograd node) against
+    get_embeddings -> Transformer -> torch.mean through the per-module Functions: the same kernels up to the token mean (the library sums
+    the tokens in order, torch.mean in its own order), so features and gradients agree to fp32 round-off; also under no_grad (the rollout
+    path: identical to the grad-mode forward)."""
+    from m3l_amd import MAEExtractor
+    from m3l_amd import functional as Fn
+    dt = "fp32" if arch.endswith("fp32") else "bf16"
+    D, fs = 128, 2
+    kw = dict(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=D, depth=2, heads=2, mlp_dim=256,
+              image_channels=3 * fs, tactile_channels=3 * fs, frame_stack=fs)
+    mkw = dict(decoder_dim=D, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, frame_stack=fs, early_conv_masking="earlyconv" in arch)
+    B = 5
+    g = torch.Generator(device="cpu").manual_seed(5)
+    obs = {"image": torch.rand(B, fs, 32, 32, 3, generator=g).to(DEV), "tactile": (torch.rand(B, fs, 6, 16, 16, generator=g) * 2 - 1).to(DEV)}
+
+    def run(fused, extra_mae_loss=False):
+        torch.manual_seed(4)
+        mae = VTMAE(encoder=VTT(**kw), compute_dtype=dt, **mkw).to(DEV)
+        ext = MAEExtractor(mae, D, arch.startswith("vision_only_control"), fs).to(DEV)
+        assert ext.vit_layer.transformer.compute_dtype == dt          # the extractor's own layer computes in the MAE's type
+        keep = Fn.FUSED_EXTRACTOR
+        Fn.FUSED_EXTRACTOR = fused
+        try:
+            with torch.no_grad():
+                f0 = ext(obs).clone()
+            f = ext(obs)
+            f.square().mean().backward()
+        finally:
+            Fn.FUSED_EXTRACTOR = keep
+        torch.cuda.synchronize()
+        return f0, f.detach().clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in ext.named_parameters()}
+
+    a0, a, ga = run(False)
+    b0, b, gb = run(True)
+    tol = 1e-5 if dt == "fp32" else 2e-2      # bf16: a last-bit difference of the pooled feature moves bf16-rounded gradients downstream
+    assert torch.equal(a0, a) and torch.equal(b0, b)
+    assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-7
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None), n
+        if ga[n] is not None:
+            scale = float(ga[n].abs().max()) + 1e-12
+            assert float((ga[n] - gb[n]).abs().max()) <= tol * scale, (n, float((ga[n] - gb[n]).abs().max()), scale)
+
 
 
 def test_dino_cat_extractor_glue_golden(golden_dir):

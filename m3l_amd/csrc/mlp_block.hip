@@ -26,6 +26,20 @@ namespace {
 #ifndef MB_ABL
 #define MB_ABL 0            // diagnostic builds only (tools/t192_ablate.sh): bits switch pieces of the forward kernel off
 #endif
+#ifndef MB_STAMP
+#define MB_STAMP 0          // diagnostic builds only: per-wave shader-clock stamps inside the forward's chunk loop (tools/mlp_phase_probe.py)
+#endif
+#if MB_STAMP
+__device__ unsigned long long* d_mb_stamps;          // [blocks][12 waves][16] accumulated cycles per loop section
+#define MB_T(i)                                                        \
+    {                                                                  \
+        const unsigned long long t_ = __builtin_readcyclecounter();    \
+        tacc[i] += t_ - tlast;                                         \
+        tlast = t_;                                                    \
+    }
+#else
+#define MB_T(i)
+#endif
 constexpr int MB_CW = 12;
 constexpr int MB_THREADS = 64 * (MB_CW + 1);
 
@@ -166,11 +180,17 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
     // order, so whenever a wave that has stores in flight needs a load's result the compiler must wait for vmcnt(0) — with b1 fetched
     // from global memory once per chunk (even a chunk ahead) that was the HBM round trip of the chunk's u / h stores, 12 times per
     // kernel.  b1 comes from LDS; the stores are never waited for inside the loop.
+#if MB_STAMP
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
     for (int c = 0; c < NC; ++c) {
         const float bias = B1S[64 * c + 16 * ct + li];
         char* US = HC + (c & 1) * 2 * Ly::HC_BYTES;
         char* HS = US + Ly::HC_BYTES;
+        MB_T(0)                                                           // loop overhead + bias read
         __builtin_amdgcn_s_barrier();                                     // W1 chunk c landed (block 2c)
+        MB_T(1)                                                           // barrier 1 (waits for the W1 block and for the slowest wave)
         if (rt < RT) {
             const char* Wb = WR + ((2 * c) % Ly::NSTAGE) * Ly::WBLK;
             const int wrow = 16 * ct + li;
@@ -178,6 +198,11 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks)
                 fw[ks].v = *reinterpret_cast<const bf16x8*>(Wb + (ks >> 1) * 8192 + wrow * 128 + ((((ks & 1) * 4 + g) ^ (wrow & 7)) << 4));
+#if MB_STAMP
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(fw[ks].v));
+#endif
+            MB_T(2)                                                       // fc1 weight fragments: 6 ds_read_b128 issued and landed
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (!(MB_ABL & 4)) {
 #pragma unroll
@@ -187,6 +212,10 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
                 }
             }
             acc = acc + acc1;
+#if MB_STAMP
+            asm volatile("" : "+v"(acc));
+#endif
+            MB_T(3)                                                       // fc1: 6 MFMAs in two chains
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bf16 ub = (bf16)(acc[r] + bias);                    // pre-activation as the backward will read it
@@ -197,7 +226,9 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MB_T(4)                                                           // bias + GELU + 8 ds_write_b16, drained
         __builtin_amdgcn_s_barrier();                                     // u / h chunk visible; W2 chunk c landed (block 2c + 1)
+        MB_T(5)                                                           // barrier 2
         // u, h chunk -> global: 128-byte row segments
         for (int id = tid; id < n * 16 && !(MB_ABL & 2); id += 64 * MB_CW) {
             const int which = id & 1, rc = id >> 1, r = rc >> 3, cc = rc & 7;
@@ -205,6 +236,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
             const uint4 v = *reinterpret_cast<const uint4*>((which ? HS : US) + r * Ly::HC_PITCH + cc * 16);
             *reinterpret_cast<uint4*>((which ? h_out : u_out) + (row0 + r) * mlp + 64 * c + cc * 8) = v;
         }
+        MB_T(6)                                                           // u / h chunk: LDS -> registers -> global stores issued
         if (rt < RT) {
             const char* Wb = WR + ((2 * c + 1) % Ly::NSTAGE) * Ly::WBLK;
             Frag<bf16> fa[2];
@@ -218,14 +250,32 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
                 for (int ks = 0; ks < 2; ++ks)
                     fw2[j][ks].v = *reinterpret_cast<const bf16x8*>(Wb + (rw >> 6) * 8192 + (rw & 63) * 128 + (((ks * 4 + g) ^ (rw & 7)) << 4));
             }
+#if MB_STAMP
+#pragma unroll
+            for (int j = 0; j < KT; ++j) { asm volatile("" : "+v"(fw2[j][0].v)); asm volatile("" : "+v"(fw2[j][1].v)); }
+#endif
+            MB_T(7)                                                       // fc2 fragments: 8 ds_read_b128 issued and landed
             if (!(MB_ABL & 4)) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int j = 0; j < KT; ++j) yacc[j] = mma16(fa[ks], fw2[j][ks], yacc[j]);
             }
+#if MB_STAMP
+#pragma unroll
+            for (int j = 0; j < KT; ++j) asm volatile("" : "+v"(yacc[j]));
+#endif
+            MB_T(8)                                                       // fc2: 6 MFMAs in three chains
         }
     }
+#if MB_STAMP
+    if (d_mb_stamps && lane == 0) {
+        unsigned long long* o = d_mb_stamps + ((long)blockIdx.x * MB_CW + wave) * 16;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[i] = tacc[i];
+        o[10] = tlast - tstart;
+    }
+#endif
     __builtin_amdgcn_s_barrier();                                         // BE1: the ring is free
     float* Y = reinterpret_cast<float*>(WR);
     constexpr int YLD = Ly::Y_PITCH / 4;
@@ -570,6 +620,9 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
     return 0;
 }
 
+#if MB_STAMP
+extern "C" int m3l_mb_set_stamps(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(d_mb_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
+#endif
 int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* u, void* h, float* xout, hipStream_t st) {
     static int inited_mlp = 0;

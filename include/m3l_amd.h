@@ -112,6 +112,11 @@ int m3l_set_t192(int on);
 /* height of the tall row tiles at width 192: 12 token tiles = 192 rows, one workgroup per CU, or 6 = 96 rows, 6 + 2 waves
  * and a 3-stage ring so that two workgroups share a CU and overlap each other's memory-only phases; env M3L_T192_TT.  Returns the previous value. */
 int m3l_set_t192_tt(int tt);
+/* 1: bf16 residual stream (opt-in, round 4; env M3L_RES_BF16): inside a transformer stack whose every layer runs on the fused kernels, the
+ * layer inputs / outputs x, x1, xout and the running residual gradient travel through HBM as bf16 instead of fp32 (registers stay fp32;
+ * the stack's input and input gradient stay fp32 at this interface).  Set it before a forward and keep it until its backward has run.
+ * Loss stays within the 1e-2 of bf16 compute; gradients carry one more bf16 rounding per half layer.  Returns the previous setting. */
+int m3l_set_residual_bf16(int on);
 /* experiment switch of the row-tiled feed-forward backward: phase-offset wave groups / static wave priority; 0, 0 = off */
 int m3l_set_t192_stagger(int lead_mask, int prio_mask);
 

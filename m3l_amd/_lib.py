@@ -49,6 +49,7 @@ _SIGS = {
     "m3l_set_t192": (c_i, [c_i]),
     "m3l_set_t192_tt": (c_i, [c_i]),
     "m3l_set_t192_stagger": (c_i, [c_i, c_i]),
+    "m3l_set_residual_bf16": (c_i, [c_i]),
     "m3l_set_defer_join": (c_i, [c_i]),
     "m3l_set_wgrad_inline": (c_i, [c_i]),
     "m3l_side_join": (c_i, [c_p]),

@@ -227,7 +227,34 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_f(x); }
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_fast(x) : gelu_grad_f(x); }
 
+// ---- the residual stream's storage type ------------------------------------------------------------
+// float (default) or bf16 (m3l_set_residual_bf16, round 4): x, x1, xout of every layer and the running residual gradient.  The
+// arithmetic on them stays fp32 in registers; only what travels through HBM is rounded (once per half layer).
+template <typename R> __device__ __forceinline__ f32x4 ld_res4(const R* p);
+template <> __device__ __forceinline__ f32x4 ld_res4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld_res4<bf16>(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ bf16x4 pack_bf16x4(f32x4 v) {
+    bf16x4 pk;
+    pk[0] = (bf16)v[0]; pk[1] = (bf16)v[1]; pk[2] = (bf16)v[2]; pk[3] = (bf16)v[3];
+    return pk;
+}
+template <typename R> __device__ __forceinline__ void st_res4(R* p, f32x4 v);
+template <> __device__ __forceinline__ void st_res4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st_res4<bf16>(bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = pack_bf16x4(v); }
+// the value as it will be read back (a layer's LayerNorm must see the x1 that the backward will see)
+template <typename R> __device__ __forceinline__ f32x4 round_res(f32x4 v) {
+    if (sizeof(R) == 4) return v;
+    const bf16x4 pk = pack_bf16x4(v);
+    return f32x4{(float)pk[0], (float)pk[1], (float)pk[2], (float)pk[3]};
+}
+
 // ---- host side -------------------------------------------------------------------------------------
+// residual-stream mode of the launch being issued (set by the transformer plan around its kernels; 0 = fp32, 1 = bf16)
+int m3l_call_rb(void);
+void m3l_set_call_rb(int rb);
 void m3l_set_error(const char* fmt, ...);
 #define M3L_CHECK(cond, ...)                 \
     do {                                     \

@@ -34,8 +34,8 @@ __device__ __forceinline__ f32x4 load4(const bf16* p) {
 }
 
 // row statistics of x[row] held in registers v[] (chunk i of this lane = elements 4*(lane+64 i) .. +3)
-template <int MAXC>
-__device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x4 (&v)[MAXC], float eps, float& mean, float& rstd) {
+template <int MAXC, typename TX>
+__device__ __forceinline__ void row_stats(const TX* xr, int D, int lane, f32x4 (&v)[MAXC], float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -57,8 +57,9 @@ __device__ __forceinline__ void row_stats(const float* xr, int D, int lane, f32x
     rstd = rsqrtf(wave_sum(q) / D + eps);
 }
 
-template <typename TO, int MAXC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ gamma,
+// TX: storage type of x (float; bf16 = the residual stream of a stack in m3l_set_residual_bf16 mode)
+template <typename TO, int MAXC, typename TX>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int M, int D, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, TO* __restrict__ y,
                                                        float* __restrict__ y32) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // LayerNorm backward.  dx_out = (dres ? dres : 0) + dLN/dx, optionally also stored in the compute type (dx_t_out: the
 // operand of the next dgrad / wgrad GEMM).  Per-block partials -> part[G][3*D]: dgamma | dbeta | column sums of dx_out
 // (= the bias gradient of the Linear whose output gradient dx_out is).
-template <typename TD, typename TC, int MAXC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, int M, int D,
+template <typename TD, typename TC, int MAXC, typename TX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const TX* __restrict__ x, int M, int D,
                                                        const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
                                                        float* __restrict__ dx_out, TC* __restrict__ dx_t_out, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float red[WPB][3][256];
@@ -1223,11 +1224,14 @@ int m3l_ln_fwd(int out_dtype, const float* x, int M, int D, const float* gamma, 
                hipStream_t st) {
     M3L_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "ln_fwd: bad shape M=%d D=%d (D must be a multiple of 4, <= 1024)", M, D);
     ProfScope prof("ln_fwd", M, D, out_dtype, (double)M * D * (4.0 + (y ? (out_dtype ? 2 : 4) : 0) + (y32 ? 4 : 0)), st);
-#define LN_FWD(TO, C) ln_fwd_kernel<TO, C><<<ln_grid(M), 256, 0, st>>>(x, M, D, gamma, beta, eps, (TO*)y, y32)
-    if (out_dtype == 1) {
-        if (D <= 256) LN_FWD(bf16, 1); else if (D <= 512) LN_FWD(bf16, 2); else LN_FWD(bf16, 4);
+#define LN_FWD(TO, C, TX) ln_fwd_kernel<TO, C, TX><<<ln_grid(M), 256, 0, st>>>((const TX*)x, M, D, gamma, beta, eps, (TO*)y, y32)
+    if (m3l_call_rb()) {          // the input is a bf16 residual stream (final LayerNorm of a stack)
+        if (out_dtype == 1) { if (D <= 256) LN_FWD(bf16, 1, bf16); else if (D <= 512) LN_FWD(bf16, 2, bf16); else LN_FWD(bf16, 4, bf16); }
+        else { if (D <= 256) LN_FWD(float, 1, bf16); else if (D <= 512) LN_FWD(float, 2, bf16); else LN_FWD(float, 4, bf16); }
+    } else if (out_dtype == 1) {
+        if (D <= 256) LN_FWD(bf16, 1, float); else if (D <= 512) LN_FWD(bf16, 2, float); else LN_FWD(bf16, 4, float);
     } else {
-        if (D <= 256) LN_FWD(float, 1); else if (D <= 512) LN_FWD(float, 2); else LN_FWD(float, 4);
+        if (D <= 256) LN_FWD(float, 1, float); else if (D <= 512) LN_FWD(float, 2, float); else LN_FWD(float, 4, float);
     }
 #undef LN_FWD
     M3L_LAUNCH_CHECK();
@@ -1263,11 +1267,15 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
     {
         ProfScope prof("ln_bwd", M, D, dy_dtype,
                        (double)M * D * (4.0 + (dy_dtype ? 2 : 4) + (dres ? 4 : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
-#define LN_BWD(TD, TC, C) ln_bwd_kernel<TD, TC, C><<<G, 256, 0, st>>>((const TD*)dy, x, M, D, gamma, eps, dres, dx_out, (TC*)dx_t_out, part_ws)
-#define LN_BWD_C(TD, TC) { if (D <= 256) LN_BWD(TD, TC, 1); else if (D <= 512) LN_BWD(TD, TC, 2); else LN_BWD(TD, TC, 4); }
-        if (dy_dtype == 1) LN_BWD_C(bf16, bf16)
-        else if (ct_dtype == 1) LN_BWD_C(float, bf16)
-        else LN_BWD_C(float, float)
+#define LN_BWD(TD, TC, C, TX) ln_bwd_kernel<TD, TC, C, TX><<<G, 256, 0, st>>>((const TD*)dy, (const TX*)x, M, D, gamma, eps, dres, dx_out, (TC*)dx_t_out, part_ws)
+#define LN_BWD_C(TD, TC, TX) { if (D <= 256) LN_BWD(TD, TC, 1, TX); else if (D <= 512) LN_BWD(TD, TC, 2, TX); else LN_BWD(TD, TC, 4, TX); }
+        if (m3l_call_rb()) {       // x is a bf16 residual stream (final LayerNorm of a stack): dres / dx_out are null, only dx_t_out is written
+            M3L_CHECK(!dres && !dx_out && dx_t_out && ct_dtype == 1, "ln_bwd: bf16 residual mode writes the compute-type gradient only");
+            if (dy_dtype == 1) LN_BWD_C(bf16, bf16, bf16) else LN_BWD_C(float, bf16, bf16)
+        }
+        else if (dy_dtype == 1) LN_BWD_C(bf16, bf16, float)
+        else if (ct_dtype == 1) LN_BWD_C(float, bf16, float)
+        else LN_BWD_C(float, float, float)
 #undef LN_BWD_C
 #undef LN_BWD
     }
@@ -1346,9 +1354,35 @@ int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out,
     return 0;
 }
 
+// 8 elements per thread (16-byte bf16 side): the boundary casts of the bf16 residual mode (count % 8 == 0, 16-byte aligned)
+__global__ void cast8_f32_bf16_kernel(const float* __restrict__ x, long n8, bf16* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 8 * i), b = *reinterpret_cast<const f32x4*>(x + 8 * i + 4);
+    bf16x8 o;
+    o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+    o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
+    *reinterpret_cast<bf16x8*>(out + 8 * i) = o;
+}
+__global__ void cast8_bf16_f32_kernel(const bf16* __restrict__ x, long n8, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + 8 * i);
+    *reinterpret_cast<f32x4*>(out + 8 * i) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *reinterpret_cast<f32x4*>(out + 8 * i + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+int m3l_cast_bf16_f32(const void* x, long count, float* out, hipStream_t st) {
+    M3L_CHECK(count % 8 == 0, "cast_bf16_f32: count %ld must be a multiple of 8", count);
+    cast8_bf16_f32_kernel<<<cdiv(count / 8, 256), 256, 0, st>>>((const bf16*)x, count / 8, out);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st) {
     ProfScope prof("cast", count, dtype, 0, (double)count * (4.0 + (dtype ? 2 : 4)), st);
-    if (dtype == 1)
+    if (dtype == 1 && count % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        cast8_f32_bf16_kernel<<<cdiv(count / 8, 256), 256, 0, st>>>(x, count / 8, (bf16*)out);
+    else if (dtype == 1)
         cast_kernel<bf16><<<cdiv(count, 256), 256, 0, st>>>(x, count, (bf16*)out);
     else
         cast_kernel<float><<<cdiv(count, 256), 256, 0, st>>>(x, count, (float*)out);

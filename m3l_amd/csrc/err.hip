@@ -21,3 +21,9 @@ extern "C" int m3l_last_error(char* buf, size_t n) {
     }
     return (int)strlen(g_err);
 }
+
+// residual-stream mode of the launch being issued (common.cuh): the transformer plan sets it around the kernels of a stack whose every
+// layer runs on kernels that support a bf16 residual stream; thread-local, as forward and backward run on different threads under autograd
+static thread_local int g_call_rb = 0;
+int m3l_call_rb(void) { return g_call_rb; }
+void m3l_set_call_rb(int rb) { g_call_rb = rb ? 1 : 0; }

@@ -148,6 +148,29 @@ inline bool drop_h() {
     if (g_drop_h < 0) g_drop_h = getenv("M3L_DROP_H") ? (atoi(getenv("M3L_DROP_H")) > 0 ? 1 : 0) : 0;
     return g_drop_h == 1;
 }
+// bf16 residual stream (round 4, opt-in: env M3L_RES_BF16 / m3l_set_residual_bf16): x, x1, xout of every layer of a stack and its running
+// residual gradient travel through HBM as bf16 instead of fp32 (fp32 in registers: the arithmetic is unchanged, each half layer's result is
+// rounded once).  The tails of the fused kernels move mostly residual-type data at ~5.5 TB/s, so halving it is direct time; the residual
+// gradient needs no separate copy at all (the compute-type copy the GEMMs read IS it).  A stack runs in this mode when every layer takes
+// kernels that support it; its input and its input gradient stay fp32 at the interface (one cast each).
+int g_res_bf16 = -1;
+inline bool res_bf16_mode() {
+    if (g_res_bf16 < 0) g_res_bf16 = getenv("M3L_RES_BF16") ? (atoi(getenv("M3L_RES_BF16")) > 0 ? 1 : 0) : 0;
+    return g_res_bf16 == 1;
+}
+struct RbScope {          // residual mode of the launches issued inside the scope (read by the launchers: m3l_call_rb)
+    explicit RbScope(bool on) { m3l_set_call_rb(on ? 1 : 0); }
+    ~RbScope() { m3l_set_call_rb(0); }
+};
+bool tf_rb(const m3l_tf_cfg* c, int B, int n, bool fuse) {
+    if (!res_bf16_mode() || c->dtype != 1 || fuse || !c->project_out || c->depth < 1) return false;
+    const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim;
+    // long sequences: per-sample attention + row-tiled feed-forward kernels, forward and backward (the MAE decoder)
+    return m3l_attn_t192_fwd_supported(1, D, c->heads, n, B) && m3l_attn_tail_mlp_t192_supported(1, D, HD, mlp, M) &&
+           !m3l_attn_block_supported(1, D, c->heads, n, c->project_out) && !m3l_mlp_block_bwd_supported(1, D, mlp, n) &&
+           m3l_qkv_bwd_t192_supported(1, D, 3 * HD, M);
+}
+
 // which fused kernel (if any) computes the feed-forward half of a layer in the FORWARD — the same decisions as m3l_transformer_fwd below:
 // 0 = per-op GEMMs (h is the operand of the fc2 GEMM: always saved), 1 = per-sample block kernel, 2 = row-tiled kernel
 // (both evaluate the fitted GELU, as every bf16 kernel does).  The backward reads it to know whether h exists and which GELU reproduces it.
@@ -394,6 +417,12 @@ int m3l_side_pending(void) {
     return (int)g_pending.size();
 }
 
+int m3l_set_residual_bf16(int on) {
+    const int old = res_bf16_mode() ? 1 : 0;
+    g_res_bf16 = on ? 1 : 0;
+    return old;
+}
+
 int m3l_set_drop_h(int on) {
     const int old = drop_h() ? 1 : 0;
     g_drop_h = on ? 1 : 0;
@@ -597,6 +626,14 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, HD) && m3l_gemm_nt_rowln_supported(dt, D, mlp);
     const void* const* tfin = tensors + 11 * c->depth;
     bool final_done = false;
+    // bf16 residual stream: the stack's input as bf16 (kept for the backward of layer 0 in the otherwise unused dxn buffer); from here on
+    // every `float*` of the residual stream points at bf16 data and the launchers are told so
+    const bool rb = tf_rb(c, B, n, fuse);
+    if (rb) {
+        if (m3l_cast_f32(1, x_in, (long)M * D, w.dxn, st)) return 1;
+        x = reinterpret_cast<const float*>(w.dxn);
+    }
+    RbScope rb_scope(rb);
     // short sequences whose every half layer takes a block kernel: the whole stack in ONE launch (enc_mega.hip)
     int l_begin = 0;
     if ((m3l_enc_mega_enabled() & 1) && !fuse && c->depth >= 1 && c->depth <= M3L_MEGA_MAX_LAYERS && c->project_out &&
@@ -745,6 +782,8 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         return slot;
     };
     const float* x_last = c->depth ? w.L[c->depth - 1].xout : x_in;
+    const bool rb = tf_rb(c, B, n, use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, mlp) && m3l_gemm_nt_rowln_supported(dt, D, 3 * HD));
+    RbScope rb_scope(rb);     // bf16 residual stream: x / x1 / xout hold bf16, the running residual gradient lives in the dx_t sets only
     const void* const* tf = tensors + 11 * c->depth;
     float* const* gf = grads + 11 * c->depth;
     // every ln_bwd also emits its result in the compute type (operand of the next GEMMs) and the column sums of it
@@ -753,7 +792,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
     if (layer_hi == c->depth) {
         float* db_last = c->depth ? grads[11 * (c->depth - 1) + 10] : nullptr;   // fc2 bias of the last layer
         const int top = c->depth ? (c->depth - 1) % NS : 0;
-        if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, w.dx, c->depth ? w.dx_t[top] : nullptr, dt,
+        if (m3l_ln_bwd(dy_dtype, dy, x_last, M, D, (const float*)tf[0], LN_EPS, nullptr, rb ? nullptr : w.dx, c->depth ? w.dx_t[top] : nullptr, dt,
                        ln_slot(2 * c->depth, gf[0], gf[1], db_last), nullptr, nullptr, nullptr, 0, st))
             return 1;
     }
@@ -844,7 +883,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         TfLayer& L = w.L[l];
         const int cur = l % NS, nxt = l ? (l - 1) % NS : 0;
-        const float* xl = l ? w.L[l - 1].xout : x_in;
+        const float* xl = l ? w.L[l - 1].xout : (rb ? reinterpret_cast<const float*>(w.dxn) : x_in);
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
         // set `cur` (dx_t[cur] was written by layer l+1's last kernel, which claimed the set) receives du / dx1_t / dqkv of this layer
@@ -862,7 +901,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         } else if (mlp_t192) {
             // long sequences: the same chain per 192-row tile; one partial row per tile
             cs_rows = m3l_mlp_t192_cs_rows(D, M);
-            if (m3l_mlp_t192_bwd(D, M, mlp, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
+            if (m3l_mlp_t192_bwd(D, M, mlp, w.dx_t[cur], rb ? nullptr : w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
                                  w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, m3l_mlp_t192_tiles(D, M)), st))
                 return 1;
         } else {
@@ -943,8 +982,16 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             // long sequences: dxn1 and the LN1 backward per 192-row tile, dxn1 never leaves the registers
             if (l && claim_set(nxt)) return 2;
             const int tiles = m3l_qkv_bwd_t192_tiles(D, M);
-            if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
-                                 ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
+            if (rb) {
+                // dres = dx1_t of this layer (bf16), result only in the compute type: the next layer's dx_t, or — layer 0 — a bf16 scratch
+                // (d_o, unused on this path) that is cast to the fp32 gradient of the stack's input
+                void* out_t = l ? w.dx_t[nxt] : w.d_o;
+                if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, reinterpret_cast<const float*>(w.dx1_t[cur]), LN_EPS,
+                                     nullptr, out_t, ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
+                    return 1;
+                if (l == 0 && dx_in && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+            } else if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
+                                        ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                 return 1;
         } else {
             e = epi0(D);

@@ -183,6 +183,12 @@ __device__ __forceinline__ void store_row8(__amdgpu_buffer_rsrc_t r, int rowoff,
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v_t, v), r, (int)((unsigned)rowoff + (unsigned)byteoff), 0, 0);
 }
 
+// 4 consecutive residual-stream elements of a row through the bounded descriptor (rowoff = byte offset of the row in R units, or ROW_OOB)
+template <typename R> __device__ __forceinline__ void store_res4(__amdgpu_buffer_rsrc_t r, int rowoff, int col, f32x4 v) {
+    if (sizeof(R) == 4) store_row16(r, rowoff, col * 4, v);
+    else store_row8(r, rowoff, col * 2, pack_bf16x4(v));
+}
+
 // sum of the CP partial accumulators of a token tile into its parity-0 wave (fixed order cp = 0, 1, ..): two barriers when CP > 1.
 // RED0: [CP - 1][TT][ND tiles][64 lanes] float4, aliasing the ring.
 template <int TT, int CP, int ND>
@@ -220,15 +226,15 @@ template <int D, int TT, int CP> struct MlpFwdLayout {
 // block c ARE the B fragment of k step c of fc1 — xn2 reaches fc1 without leaving the registers (it is still written out once, for
 // the weight-gradient GEMM), and x1 is written for the residual add at the end and for the backward.
 struct ProArgs {
-    const bf16* o; const float* x; const bf16* Wo; const float* bo; const float* ln_w; const float* ln_b; float eps;
-    float* x1_out; bf16* xn2_out;
+    const bf16* o; const void* x; const bf16* Wo; const float* bo; const float* ln_w; const float* ln_b; float eps;      // x, x1_out: residual type
+    void* x1_out; bf16* xn2_out;
 };
-template <int D, int TT, int CP, int PRO>
-__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+template <int D, int TT, int CP, int PRO, typename R>
+__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_fwd_kernel(const bf16* __restrict__ xn2, const R* __restrict__ x1,
                                                                    const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                    const bf16* __restrict__ W2, const float* __restrict__ b2, int M, int mlp,
                                                                    bf16* __restrict__ u_out, bf16* __restrict__ h_out,
-                                                                   float* __restrict__ xout, ProArgs pro) {
+                                                                   R* __restrict__ xout, ProArgs pro) {
     static_assert(!PRO || CP == 1, "the fused out-proj prologue needs one parity");
     using Cf = TileCfg<D, TT, CP>;
     constexpr int NCW = Cf::NCW, KS = Cf::KS, ND = Cf::ND;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
     const long trow = row0 + 16 * tw + li;                    // this lane's token (column of every accumulator tile)
     const bool ok = trow < M;
     const long lrow = ok ? trow : (long)M - 1;                // a valid row for the unconditional loads of a token past the end
-    const int xoff = ok ? (int)(trow * D * 4) : ROW_OOB;      // byte offset of the token's fp32 row for the bounded stores (past the bound: dropped)
+    const int xoff = ok ? (int)(trow * D * sizeof(R)) : ROW_OOB;      // byte offset of the token's residual row for the bounded stores (past the bound: dropped)
     for (int id = tid; id < mlp; id += 64 * NCW) B1[id] = b1[id];                 // shared: the first ring barrier orders them
     for (int id = tid; id < D; id += 64 * NCW) B2[id] = b2[id];
     float* PV = B2 + D;                                       // PRO: bo | ln_w | ln_b, read after the prologue's stage barriers
@@ -288,7 +294,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = 32 * c + 8 * g + 4 * t;
-                pa[c][t] = *reinterpret_cast<const f32x4*>(pro.x + lrow * D + col) + *reinterpret_cast<const f32x4*>(pro.bo + col);
+                pa[c][t] = ld_res4<R>(reinterpret_cast<const R*>(pro.x) + lrow * D + col) + *reinterpret_cast<const f32x4*>(pro.bo + col);
             }
 #pragma unroll
         for (int s0 = 0; s0 < PRO_STAGES; ++s0) {
@@ -306,15 +312,16 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
             }
         }
         // x1 leaves (for the residual add at the end and for the backward); LayerNorm over the token (in-lane sums + the 4 lane groups)
-        const __amdgpu_buffer_rsrc_t rx1 = rows_rsrc(pro.x1_out, (long)M * D * 4);
+        const __amdgpu_buffer_rsrc_t rx1 = rows_rsrc(pro.x1_out, (long)M * D * sizeof(R));
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < KS; ++c)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = 32 * c + 8 * g + 4 * t;
-                const f32x4 v = pa[c][t];
-                store_row16(rx1, xoff, col * 4, v);
+                const f32x4 v = round_res<R>(pa[c][t]);           // x1 as the backward will read it
+                if (sizeof(R) == 2) pa[c][t] = v;
+                store_res4<R>(rx1, xoff, col, v);
                 sum += (v[0] + v[1]) + (v[2] + v[3]);
             }
         const float mean = col4_sum(sum) * (1.0f / D);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
             }
             if (ok) *reinterpret_cast<bf16x8*>(pro.xn2_out + trow * D + 32 * c + 8 * g) = xb[c].v;
         }
-        x1 = pro.x1_out;                                      // residual operand of the epilogue (written above by this lane's token)
+        x1 = reinterpret_cast<const R*>(pro.x1_out);          // residual operand of the epilogue (written above by this lane's token)
     }
 
     f32x4 yacc[ND];
@@ -419,14 +426,14 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
         // xout and kept load d behind store d - 1: twelve round trips at the end of the kernel)
         f32x4 r1[ND];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) r1[d] = *reinterpret_cast<const f32x4*>(x1 + lrow * D + 16 * d + 4 * g);
+        for (int d = 0; d < ND; ++d) r1[d] = ld_res4<R>(x1 + lrow * D + 16 * d + 4 * g);
         asm volatile("" ::: "memory");
-        const __amdgpu_buffer_rsrc_t rxo = rows_rsrc(xout, (long)M * D * 4);
+        const __amdgpu_buffer_rsrc_t rxo = rows_rsrc(xout, (long)M * D * sizeof(R));
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int col = 16 * d + 4 * g;
             const f32x4 v = yacc[d] + *reinterpret_cast<const f32x4*>(B2 + col) + r1[d];
-            store_row16(rxo, xoff, col * 4, v);
+            store_res4<R>(rxo, xoff, col, v);
         }
     }
 }
@@ -451,9 +458,9 @@ template <int D, int TT, int CP> struct MlpBwdLayout {
 // column sums of (dy * xhat | dy | out) -> LP[wave][3 D] at `lp_base` (a region every wave has stopped using: barrier T1 inside;
 // T2 after the partials are written).  active = false: the wave only keeps the two barriers (rows past M, parities > 0).
 // Token sums = 48 registers + 2 shuffles; sums over the 16 tokens of a column = one DPP row reduction.
-template <int ND>
-__device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float* __restrict__ x, const float* G,
-                                            const float* __restrict__ dres, float* __restrict__ dx_out, bf16* __restrict__ dxt_out, float eps,
+template <int ND, typename R>
+__device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const R* __restrict__ x, const float* G,
+                                            const R* __restrict__ dres, R* __restrict__ dx_out, bf16* __restrict__ dxt_out, float eps,
                                             long trow, long lrow, long M, bool active, char* lp_base, int wave, int lane) {
     constexpr int T_D = 16 * ND;
     const int g = lane >> 4, li = lane & 15;
@@ -467,13 +474,13 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
     constexpr int BT = ND % 6 == 0 ? 6 : 4;                   // row pieces requested per batch
     static_assert(ND % BT == 0, "ND is a multiple of the batch");
     const bool use = active && !(T192_ABL & 32);
-    const float* xr = x + lrow * T_D + 4 * g;                 // (not const-qualified as a variable: laundered between the passes)
+    const R* xr = x + lrow * T_D + 4 * g;                     // (not const-qualified as a variable: laundered between the passes)
     float s = 0.f;
 #pragma unroll
     for (int d0 = 0; d0 < ND; d0 += BT) {
         f32x4 v[BT];
 #pragma unroll
-        for (int j = 0; j < BT; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
+        for (int j = 0; j < BT; ++j) v[j] = ld_res4<R>(xr + 16 * (d0 + j));
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
             if (!use) v[j] = f32x4{0.f, 0.f, 0.f, (float)(d0 + j)};
@@ -487,7 +494,7 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
     for (int d0 = 0; d0 < ND; d0 += BT) {
         f32x4 v[BT];
 #pragma unroll
-        for (int j = 0; j < BT; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
+        for (int j = 0; j < BT; ++j) v[j] = ld_res4<R>(xr + 16 * (d0 + j));
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
             const int d = d0 + j;
@@ -506,18 +513,18 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
     asm volatile("" : "+v"(xr));                              // (an opaque copy: the re-reads must not be merged with the first pass's loads)
     __builtin_amdgcn_s_barrier();                             // T1: every wave is done with the region LP aliases
     float* LP = reinterpret_cast<float*>(lp_base) + wave * 3 * T_D;
-    const int roff32 = use ? (int)(trow * T_D * 4) : ROW_OOB, roff16 = use ? (int)(trow * T_D * 2) : ROW_OOB;
-    const __amdgpu_buffer_rsrc_t rdx = rows_rsrc(dx_out, M * T_D * 4), rdt = rows_rsrc(dxt_out, M * T_D * 2);
+    const int roff32 = use ? (int)(trow * T_D * sizeof(R)) : ROW_OOB, roff16 = use ? (int)(trow * T_D * 2) : ROW_OOB;
+    const __amdgpu_buffer_rsrc_t rdx = rows_rsrc(dx_out, M * T_D * sizeof(R)), rdt = rows_rsrc(dxt_out, M * T_D * 2);     // (a null dx_out: bound 0, stores dropped)
     constexpr int BO = 4;                                     // (x, dres) pairs per batch of the output pass
     static_assert(ND % BO == 0, "ND is a multiple of the batch");
-    const float* dr_ = dres + lrow * T_D + 4 * g;
+    const R* dr_ = dres + lrow * T_D + 4 * g;
 #pragma unroll
     for (int d0 = 0; d0 < ND; d0 += BO) {
         f32x4 v[BO], dr[BO];
 #pragma unroll
         for (int j = 0; j < BO; ++j) {
-            v[j] = *reinterpret_cast<const f32x4*>(xr + 16 * (d0 + j));
-            dr[j] = *reinterpret_cast<const f32x4*>(dr_ + 16 * (d0 + j));
+            v[j] = ld_res4<R>(xr + 16 * (d0 + j));
+            dr[j] = ld_res4<R>(dr_ + 16 * (d0 + j));
         }
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -529,7 +536,7 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
             f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
             if (active) rr = (gd - s1 - xh * s2) * rstd;
             if (use) rr += dr[j];
-            store_row16(rdx, roff32, col * 4, rr);
+            store_res4<R>(rdx, roff32, col, rr);
             bf16x4 pk;
             pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
             store_row8(rdt, roff16, col * 2, pk);
@@ -550,9 +557,9 @@ __device__ __forceinline__ void ln_bwd_rows(const f32x4 (&yacc)[ND], const float
     __builtin_amdgcn_s_barrier();                             // T2: partials complete
 }
 
-template <int D, int TT, int CP>
-__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
-                                                                   const float* __restrict__ x1, const float* __restrict__ ln2_w,
+template <int D, int TT, int CP, typename R>
+__global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>::MINW)) void mlp_t192_bwd_kernel(const bf16* __restrict__ dxt, R* __restrict__ dx,
+                                                                   const R* __restrict__ x1, const float* __restrict__ ln2_w,
                                                                    const bf16* __restrict__ u, const bf16* __restrict__ W2T,
                                                                    const bf16* __restrict__ W1T, float eps, int M, int mlp,
                                                                    bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
@@ -655,8 +662,13 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
         }
     }
     reduce_to_parity0<TT, CP, ND>(RING, tw, cp, lane, yacc); // (two barriers when CP > 1)
-    // ---- LN2 backward on the registers (parity-0 waves; the others only keep the barrier count): T1, T2 inside
-    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok && cp == 0, RING, wave, lane);
+    // ---- LN2 backward on the registers (parity-0 waves; the others only keep the barrier count): T1, T2 inside.  bf16 residual stream:
+    // the incoming residual gradient IS dxt (no separate fp32 copy exists) and only the compute-type result is written
+    {
+        const R* dres = dx;
+        if (sizeof(R) == 2) dres = reinterpret_cast<const R*>(dxt);
+        ln_bwd_rows<ND, R>(yacc, x1, G, dres, sizeof(R) == 2 ? nullptr : dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok && cp == 0, RING, wave, lane);
+    }
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * D; id += 64 * NCW) {
@@ -780,7 +792,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, CP>::THREADS), (TileCfg<D, TT, CP>:
         dprev = dub;
     }
     p3(RING + ((NC - 1) % Cf::NSTAGE) * Cf::STAGE + Cf::BLK);     // the last chunk's second product (the ring is no longer overwritten)
-    ln_bwd_rows(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);
+    ln_bwd_rows<ND, float>(yacc, x1, G, dx, dx, dx1t_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * D; id += 64 * NCW) {
@@ -809,11 +821,11 @@ template <int D, int TT> struct QkvBwdLayout {
     static constexpr size_t TOTAL = (size_t)G + D * 4;
 };
 
-template <int D, int TT>
-__global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS), (TileCfg<D, TT, 1>::MINW)) void qkv_bwd_t192_kernel(const bf16* __restrict__ dqkv, const float* __restrict__ x,
+template <int D, int TT, typename R>
+__global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS), (TileCfg<D, TT, 1>::MINW)) void qkv_bwd_t192_kernel(const bf16* __restrict__ dqkv, const R* __restrict__ x,
                                                                                const float* __restrict__ ln1_w, const bf16* __restrict__ WqkvT,
-                                                                               const float* __restrict__ dres, float eps, int M, int K,
-                                                                               float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+                                                                               const R* __restrict__ dres, float eps, int M, int K,
+                                                                               R* __restrict__ dx_out, bf16* __restrict__ dxt_out,
                                                                                float* __restrict__ ln_part) {
     using Cf = TileCfg<D, TT, 1>;
     constexpr int NCW = Cf::NCW, ND = Cf::ND;
@@ -868,7 +880,7 @@ __global__ __launch_bounds__((TileCfg<D, TT, 1>::THREADS), (TileCfg<D, TT, 1>::M
             yacc[d] = mma16(fa[1], b1, yacc[d]);
         }
     }
-    ln_bwd_rows(yacc, x, G, dres, dx_out, dxt_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);      // barriers T1, T2
+    ln_bwd_rows<ND, R>(yacc, x, G, dres, dx_out, dxt_out, eps, trow, ok ? trow : (long)M - 1, M, ok, RING, wave, lane);      // barriers T1, T2
     {
         const float* LP0 = reinterpret_cast<const float*>(RING);
         for (int id = tid; id < 3 * D; id += 64 * NCW) {
@@ -897,8 +909,8 @@ template <int D> struct AttnFwdLayout {
 };
 
 // D = 64 H (192 / 3 heads: the MAE decoder of cfg 2; 256 / 4 heads: M3L's default decoder, train.py:146-153)
-template <int D, int H>
-__global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+template <int D, int H, typename R>
+__global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_kernel(const R* __restrict__ x, const float* __restrict__ ln_w,
                                                                                 const float* __restrict__ ln_b, const bf16* __restrict__ Wqkv,
                                                                                 float eps, int n, bf16* __restrict__ xn1_out,
                                                                                 bf16* __restrict__ qkv_out, bf16* __restrict__ o_out,
@@ -947,12 +959,12 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_fwd_ke
     Frag<bf16> xb[KS];
     {
         // the row in one batch of unconditional loads (a token past n reads the sample's last row and drops it: see load_tok_frags)
-        const float* xrow = x + (ok ? trow : row0 + n - 1) * D + 8 * g;
+        const R* xrow = x + (ok ? trow : row0 + n - 1) * D + 8 * g;
         f32x4 v[KS][2];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) v[ks][t] = *reinterpret_cast<const f32x4*>(xrow + 32 * ks + 4 * t);
+            for (int t = 0; t < 2; ++t) v[ks][t] = ld_res4<R>(xrow + 32 * ks + 4 * t);
         float sum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -1387,6 +1399,12 @@ template <typename K> static int lds_attr(K kern, size_t bytes) {
     else if ((DV) == 256) { constexpr int D = 256, TT = WideTile<256>::TT, CP = 1; __VA_ARGS__; }      \
     else { constexpr int D = 384, TT = WideTile<384>::TT, CP = 1; __VA_ARGS__; }
 
+// residual-stream type of the launch (m3l_call_rb(): set by the transformer plan around its kernels): the float* residual arguments of the
+// launchers below then point at bf16 data
+#define T192_RES(...)                                            \
+    if (m3l_call_rb()) { using R = bf16; __VA_ARGS__; }           \
+    else { using R = float; __VA_ARGS__; }
+
 int m3l_mlp_t192_fwd(int Dm, int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "mlp_t192_fwd: width %d", Dm);
@@ -1394,11 +1412,11 @@ int m3l_mlp_t192_fwd(int Dm, int M, int mlp, const void* xn2, const float* x1, c
     ProfScope prof("mlp_t192_fwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 2.0 + Dm * 8.0 + mlp * 4.0));
     ProArgs none;
     memset(&none, 0, sizeof(none));
-    T192_DISPATCH(Dm, tt, {
-        LDS_ONCE((mlp_t192_fwd_kernel<D, TT, CP, 0>), (MlpFwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
-        mlp_t192_fwd_kernel<D, TT, CP, 0><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpFwdLayout<D, TT, CP>::total(mlp), st>>>(
-            (const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout, none);
-    });
+    T192_DISPATCH(Dm, tt, T192_RES({
+        LDS_ONCE((mlp_t192_fwd_kernel<D, TT, CP, 0, R>), (MlpFwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
+        mlp_t192_fwd_kernel<D, TT, CP, 0, R><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpFwdLayout<D, TT, CP>::total(mlp), st>>>(
+            (const bf16*)xn2, (const R*)x1, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, (R*)xout, none);
+    }));
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1415,11 +1433,11 @@ int m3l_attn_tail_mlp_t192_fwd(int Dm, int M, int mlp, const void* o, const floa
     ProfScope prof("attn_tail_mlp_t192_fwd", M, mlp, Dm == 192 ? tall_tt() : tile_rows(Dm, M) / 16, 4.0 * M * (double)Dm * mlp + 2.0 * M * (double)Dm * Dm, st,
                    (double)M * (Dm * 2.0 + Dm * 4.0 + Dm * 4.0 + Dm * 2.0 + Dm * 8.0 + mlp * 4.0));
     ProArgs pa = {(const bf16*)o, x, (const bf16*)wo, bo, ln2_w, ln2_b, eps, x1, (bf16*)xn2};
-    T192_DISPATCH_FULL(Dm, {
-        LDS_ONCE((mlp_t192_fwd_kernel<D, TT, CP, 1>), (MlpFwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
-        mlp_t192_fwd_kernel<D, TT, CP, 1><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpFwdLayout<D, TT, CP>::total(mlp), st>>>(
-            nullptr, nullptr, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, xout, pa);
-    });
+    T192_DISPATCH_FULL(Dm, T192_RES({
+        LDS_ONCE((mlp_t192_fwd_kernel<D, TT, CP, 1, R>), (MlpFwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
+        mlp_t192_fwd_kernel<D, TT, CP, 1, R><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpFwdLayout<D, TT, CP>::total(mlp), st>>>(
+            nullptr, nullptr, (const bf16*)w1, b1, (const bf16*)w2, b2, M, mlp, (bf16*)u, (bf16*)h, (R*)xout, pa);
+    }));
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1429,14 +1447,14 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
     M3L_CHECK(width_ok(Dm), "mlp_t192_bwd: width %d", Dm);
     const int tt = Dm == 192 ? t192_tt(M) : tile_rows(Dm, M) / 16;
     ProfScope prof("mlp_t192_bwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 4.0 + Dm * 12.0 + mlp * 4.0));
-    T192_DISPATCH(Dm, tt, {
-        LDS_ONCE((mlp_t192_bwd_kernel<D, TT, CP>), (MlpBwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
+    T192_DISPATCH(Dm, tt, T192_RES({
+        LDS_ONCE((mlp_t192_bwd_kernel<D, TT, CP, R>), (MlpBwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
         M3L_CHECK((MlpBwdLayout<D, TT, CP>::total(mlp)) <= (size_t)160 * 1024, "mlp_t192_bwd: %zu bytes of LDS", (MlpBwdLayout<D, TT, CP>::total(mlp)));
         // experiment knobs: M3L_T192_STG = mask of the compute waves that run the deferred product FIRST (0x1000 = staggered kernel, none lead),
         // M3L_T192_PRIO = mask of the waves that raise their priority
         stg_init();
         const int stg = g_stg, prio = g_prio;
-        if constexpr (D == 192 && TT == 12 && CP == 1 && T192_NS_TALL == 4) {
+        if constexpr (D == 192 && TT == 12 && CP == 1 && T192_NS_TALL == 4 && sizeof(R) == 4) {
             if (stg || prio) {
                 LDS_ONCE((mlp_t192_bwd_stg_kernel<D, TT, CP>), (MlpBwdLayout<D, TT, CP>::total(1024)));
                 mlp_t192_bwd_stg_kernel<D, TT, CP><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
@@ -1446,10 +1464,10 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
                 return 0;
             }
         }
-        mlp_t192_bwd_kernel<D, TT, CP><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
-            (const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t, cs_part,
+        mlp_t192_bwd_kernel<D, TT, CP, R><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, MlpBwdLayout<D, TT, CP>::total(mlp), st>>>(
+            (const bf16*)dxt, (R*)dx, (const R*)x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T, eps, M, mlp, (bf16*)du, (bf16*)dx1t, cs_part,
             ln_part);
-    });
+    }));
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1465,11 +1483,11 @@ int m3l_qkv_bwd_t192(int Dm, int M, int K, const void* dqkv, const float* x, con
                      float* dx_out, void* dxt_out, float* ln_part, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "qkv_bwd_t192: width %d", Dm);
     ProfScope prof("qkv_bwd_t192", M, K, Dm, 2.0 * M * (double)Dm * K, st, (double)M * (K * 2.0 + Dm * 14.0));
-    T192_DISPATCH_FULL(Dm, {
-        LDS_ONCE((qkv_bwd_t192_kernel<D, TT>), (QkvBwdLayout<D, TT>::TOTAL));
-        qkv_bwd_t192_kernel<D, TT><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, QkvBwdLayout<D, TT>::TOTAL, st>>>(
-            (const bf16*)dqkv, x, ln1_w, (const bf16*)wqkvT, dres, eps, M, K, dx_out, (bf16*)dxt_out, ln_part);
-    });
+    T192_DISPATCH_FULL(Dm, T192_RES({
+        LDS_ONCE((qkv_bwd_t192_kernel<D, TT, R>), (QkvBwdLayout<D, TT>::TOTAL));
+        qkv_bwd_t192_kernel<D, TT, R><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, QkvBwdLayout<D, TT>::TOTAL, st>>>(
+            (const bf16*)dqkv, (const R*)x, ln1_w, (const bf16*)wqkvT, (const R*)dres, eps, M, K, (R*)dx_out, (bf16*)dxt_out, ln_part);
+    }));
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1487,13 +1505,17 @@ int m3l_attn_t192_fwd(int Dm, int B, int n, const float* x, const float* ln_w, c
     ProfScope prof("attn_t192_fwd", B, n, Dm, 2.0 * B * n * 3.0 * Dm * Dm + 4.0 * B * H * (double)n * n * 64, st,
                    (double)B * n * (Dm * 4.0 + Dm * 2.0 + 3.0 * Dm * 2.0 + Dm * 2.0));
     if (Dm == 192) {
-        LDS_ONCE((attn_t192_fwd_kernel<192, 3>), (AttnFwdLayout<192>::TOTAL));
-        attn_t192_fwd_kernel<192, 3><<<B, TileCfg<192, 12, 1>::THREADS, AttnFwdLayout<192>::TOTAL, st>>>(x, ln_w, ln_b, (const bf16*)wqkv, eps, n, (bf16*)xn1,
-                                                                                                   (bf16*)qkv, (bf16*)o, lse);
+        T192_RES({
+            LDS_ONCE((attn_t192_fwd_kernel<192, 3, R>), (AttnFwdLayout<192>::TOTAL));
+            attn_t192_fwd_kernel<192, 3, R><<<B, TileCfg<192, 12, 1>::THREADS, AttnFwdLayout<192>::TOTAL, st>>>((const R*)x, ln_w, ln_b, (const bf16*)wqkv, eps, n,
+                                                                                                          (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse);
+        });
     } else {
-        LDS_ONCE((attn_t192_fwd_kernel<256, 4>), (AttnFwdLayout<256>::TOTAL));
-        attn_t192_fwd_kernel<256, 4><<<B, TileCfg<256, 12, 1>::THREADS, AttnFwdLayout<256>::TOTAL, st>>>(x, ln_w, ln_b, (const bf16*)wqkv, eps, n, (bf16*)xn1,
-                                                                                                   (bf16*)qkv, (bf16*)o, lse);
+        T192_RES({
+            LDS_ONCE((attn_t192_fwd_kernel<256, 4, R>), (AttnFwdLayout<256>::TOTAL));
+            attn_t192_fwd_kernel<256, 4, R><<<B, TileCfg<256, 12, 1>::THREADS, AttnFwdLayout<256>::TOTAL, st>>>((const R*)x, ln_w, ln_b, (const bf16*)wqkv, eps, n,
+                                                                                                          (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse);
+        });
     }
     M3L_LAUNCH_CHECK();
     return 0;

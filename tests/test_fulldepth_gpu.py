@@ -157,6 +157,19 @@ def test_cfg2_full_depth_at_the_bench_kernel_selection(mode):
         assert any(k.startswith(want) for k in kinds), (want, sorted(kinds))
 
 
+def test_cfg2_bf16_residual_stream_vs_oracle():
+    """m3l_set_residual_bf16(1) (opt-in): the layer inputs / outputs and the residual gradient of the fused stacks travel
+    as bf16.  cfg 2 at full depth, B = 128 (the bench's kernel selection), against the fp32 oracle: mask indices bit-exact, loss within
+    north_star's 1e-2; the gradient bounds are this mode's own (3x what it measures), wider than the fp32-residual ones."""
+    lib = L.lib()
+    old = lib.m3l_set_residual_bf16(1)
+    try:
+        rel, worst, l2 = _check(CFG2, "cfg2_b128", 128, "bf16", 1, 1e-2, 0.1, 3e-2)
+    finally:
+        lib.m3l_set_residual_bf16(old)
+    print(f"\n[fulldepth] bf16 residual stream: loss rel {rel:.2e}, worst grad {worst}, rel-L2 {l2:.2e}")
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_cfg4_full_depth_vs_oracle(dt):
     if dt == "fp32":

@@ -51,12 +51,12 @@ template <int KT> struct AbLayout {
 };
 
 // (the body is a device function: attn_block_fwd_kernel wraps it, and enc_mega.hip calls it for every layer of a stack in one launch)
-template <int KT>
+template <int KT, typename R>
 __device__ M3L_BODY_INLINE void attn_block_fwd_body(
-    const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
+    const R* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
     const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
     float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
-    float* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
+    R* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
     using Ly = AbLayout<KT>;
     constexpr int D = Ly::D, H = KT, KSTEPS = 2 * KT;
     constexpr int NB_QKV = 3 * KT, NB = 4 * KT;          // 64-row weight blocks: Wqkv then Wo
@@ -128,7 +128,7 @@ __device__ M3L_BODY_INLINE void attn_block_fwd_body(
         f32x4 xr[KT];
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
-            xr[c] = (r < n) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xr[c] = (r < n) ? ld_res4<R>(x + (row0 + r) * D + 4 * (li + 16 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
             x0[c] = xr[c];
         }
         float s1 = 0.f;
@@ -335,8 +335,8 @@ __device__ M3L_BODY_INLINE void attn_block_fwd_body(
         for (int c = 0; c < KT; ++c) {
             v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                v[c] = *reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) + bor[c] + x0[c];
-                *reinterpret_cast<f32x4*>(x1_out + (row0 + r) * D + 4 * (li + 16 * c)) = v[c];
+                v[c] = round_res<R>(*reinterpret_cast<const f32x4*>(Y + r * YLD + 4 * (li + 16 * c)) + bor[c] + x0[c]);     // x1 as the backward reads it
+                st_res4<R>(x1_out + (row0 + r) * D + 4 * (li + 16 * c), v[c]);
             }
             s1 += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
@@ -363,13 +363,13 @@ __device__ M3L_BODY_INLINE void attn_block_fwd_body(
 }
 
 #ifndef M3L_BLOCK_BODIES_ONLY
-template <int KT>
+template <int KT, typename R>
 __global__ __launch_bounds__(AB_THREADS) void attn_block_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
+    const R* __restrict__ x, const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16* __restrict__ Wqkv,
     const bf16* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
     float eps, int n, bf16* __restrict__ xn1_out, bf16* __restrict__ qkv_out, bf16* __restrict__ o_out, float* __restrict__ lse_out,
-    float* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
-    attn_block_fwd_body<KT>(x, ln1_w, ln1_b, Wqkv, Wo, bo, ln2_w, ln2_b, eps, n, xn1_out, qkv_out, o_out, lse_out, x1_out, xn2_out, phase_ts);
+    R* __restrict__ x1_out, bf16* __restrict__ xn2_out, unsigned long long* __restrict__ phase_ts) {
+    attn_block_fwd_body<KT, R>(x, ln1_w, ln1_b, Wqkv, Wo, bo, ln2_w, ln2_b, eps, n, xn1_out, qkv_out, o_out, lse_out, x1_out, xn2_out, phase_ts);
 }
 
 int g_ab_state = 0;   // 0 = unknown, 1 = on, -1 = off
@@ -401,11 +401,13 @@ template <int KT> struct AbBwdLayout {
     static_assert(AB_CW * 3 * D * 4 <= A_BYTES + NT * T_BYTES, "LayerNorm partials reuse the tile region");
 };
 
-template <int KT>
+// R = storage type of the residual stream (x, dres, dx_out).  bf16: dres is not read — the incoming residual gradient IS dx1t — and dx_out is
+// not written (only the compute-type result dxt_out, which must then be given)
+template <int KT, typename R>
 __device__ M3L_BODY_INLINE void attn_block_bwd_body(
-    const bf16* __restrict__ dx1t, const float* __restrict__ dres, const float* __restrict__ x, const float* __restrict__ ln1_w,
+    const bf16* __restrict__ dx1t, const R* __restrict__ dres, const R* __restrict__ x, const float* __restrict__ ln1_w,
     const bf16* __restrict__ qkv, const bf16* __restrict__ o, const float* __restrict__ lse, const bf16* __restrict__ WoT,
-    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, R* __restrict__ dx_out, bf16* __restrict__ dxt_out,
     float* __restrict__ ln_part) {
     using Ly = AbBwdLayout<KT>;
     constexpr int D = Ly::D, H = KT, KSTEPS = 2 * KT, NB = 4 * KT, NDMA = 8 * KT, TP = Ly::T_PITCH, TLD = TP / 2;
@@ -720,8 +722,9 @@ __device__ M3L_BODY_INLINE void attn_block_bwd_body(
             for (int c = 0; c < KT; ++c) {
                 const int col = 4 * (li + 16 * c);
                 gm_t[c] = *reinterpret_cast<const f32x4*>(ln1_w + col);
-                xr_t[c] = r < n ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                dr_t[c] = r < n ? *reinterpret_cast<const f32x4*>(dres + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                xr_t[c] = r < n ? ld_res4<R>(x + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (sizeof(R) == 2) dr_t[c] = r < n ? ld_res4<bf16>(dx1t + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                else dr_t[c] = r < n ? ld_res4<R>(dres + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         // ---- dxn1 += dq_h Wqkv[q_h cols] + dk_h Wqkv[k_h cols] + dv_h Wqkv[v_h cols]: blocks 4h + 1 .. 4h + 3
@@ -801,7 +804,7 @@ __device__ M3L_BODY_INLINE void attn_block_bwd_body(
             f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 rr = (gd[c] - s1 - xh[c] * s2) * rstd + dr_t[c];
-                *reinterpret_cast<f32x4*>(dx_out + (row0 + r) * D + col) = rr;
+                if (sizeof(R) == 4) st_res4<R>(dx_out + (row0 + r) * D + col, rr);
                 if (dxt_out) {
                     bf16x4 pk;
                     pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
@@ -833,13 +836,13 @@ __device__ M3L_BODY_INLINE void attn_block_bwd_body(
 }
 
 #ifndef M3L_BLOCK_BODIES_ONLY
-template <int KT>
+template <int KT, typename R>
 __global__ __launch_bounds__(AB_THREADS) void attn_block_bwd_kernel(
-    const bf16* __restrict__ dx1t, const float* __restrict__ dres, const float* __restrict__ x, const float* __restrict__ ln1_w,
+    const bf16* __restrict__ dx1t, const R* __restrict__ dres, const R* __restrict__ x, const float* __restrict__ ln1_w,
     const bf16* __restrict__ qkv, const bf16* __restrict__ o, const float* __restrict__ lse, const bf16* __restrict__ WoT,
-    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, float* __restrict__ dx_out, bf16* __restrict__ dxt_out,
+    const bf16* __restrict__ WqkvT, float eps, int n, bf16* __restrict__ dqkv_out, R* __restrict__ dx_out, bf16* __restrict__ dxt_out,
     float* __restrict__ ln_part) {
-    attn_block_bwd_body<KT>(dx1t, dres, x, ln1_w, qkv, o, lse, WoT, WqkvT, eps, n, dqkv_out, dx_out, dxt_out, ln_part);
+    attn_block_bwd_body<KT, R>(dx1t, dres, x, ln1_w, qkv, o, lse, WoT, WqkvT, eps, n, dqkv_out, dx_out, dxt_out, ln_part);
 }
 #endif
 
@@ -884,18 +887,22 @@ int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, 
                        float* x1, void* xn2, hipStream_t st) {
     static int inited = 0;
     if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<2>::TOTAL));
-        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<3>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<3>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<2, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<3>::TOTAL));
         inited = 1;
     }
     ProfScope prof("attn_block_fwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64, st);
-#define AB_LAUNCH(KT)                                                                                                              \
-    attn_block_fwd_kernel<KT><<<B, AB_THREADS, AbLayout<KT>::TOTAL, st>>>(x, ln1_w, ln1_b, (const bf16*)wqkv, (const bf16*)wo, bo, ln2_w, \
-                                                                         ln2_b, eps, n, (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse, x1, (bf16*)xn2, \
-                                                                         g_attn_phase_ts)
+    // (m3l_call_rb(): the residual stream x / x1 of this launch is bf16)
+#define AB_LAUNCH(KT, R)                                                                                                              \
+    attn_block_fwd_kernel<KT, R><<<B, AB_THREADS, AbLayout<KT>::TOTAL, st>>>((const R*)x, ln1_w, ln1_b, (const bf16*)wqkv, (const bf16*)wo, bo, ln2_w, \
+                                                                            ln2_b, eps, n, (bf16*)xn1, (bf16*)qkv, (bf16*)o, lse, (R*)x1, (bf16*)xn2, \
+                                                                            g_attn_phase_ts)
     M3L_CHECK(D == 128 || D == 192, "attn_block: D=%d unsupported", D);
-    if (D == 128) AB_LAUNCH(2);
-    else AB_LAUNCH(3);
+    if (m3l_call_rb()) { if (D == 128) AB_LAUNCH(2, bf16); else AB_LAUNCH(3, bf16); }
+    else if (D == 128) AB_LAUNCH(2, float);
+    else AB_LAUNCH(3, float);
 #undef AB_LAUNCH
     M3L_LAUNCH_CHECK();
     return 0;
@@ -906,18 +913,22 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
                        float* ln_part, hipStream_t st) {
     static int inited = 0;
     if (!inited) {
-        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<2>::TOTAL));
-        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<3>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<3>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<2, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<2>::TOTAL));
+        M3L_HIP(hipFuncSetAttribute((const void*)attn_block_bwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, AbBwdLayout<3>::TOTAL));
         inited = 1;
     }
     M3L_CHECK(D == 128 || D == 192, "attn_block_bwd: D=%d unsupported", D);
+    M3L_CHECK(!m3l_call_rb() || dxt_out, "attn_block_bwd: the bf16 residual mode writes its result to dxt_out only");
     ProfScope prof("attn_block_bwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64, st);
-#define ABB_LAUNCH(KT)                                                                                                               \
-    attn_block_bwd_kernel<KT><<<B, AB_THREADS, AbBwdLayout<KT>::TOTAL, st>>>((const bf16*)dx1t, dres, x, ln1_w, (const bf16*)qkv, (const bf16*)o, lse, \
-                                                                            (const bf16*)woT, (const bf16*)wqkvT, eps, n, (bf16*)dqkv, dx_out,      \
-                                                                            (bf16*)dxt_out, ln_part)
-    if (D == 128) ABB_LAUNCH(2);
-    else ABB_LAUNCH(3);
+#define ABB_LAUNCH(KT, R)                                                                                                               \
+    attn_block_bwd_kernel<KT, R><<<B, AB_THREADS, AbBwdLayout<KT>::TOTAL, st>>>((const bf16*)dx1t, (const R*)dres, (const R*)x, ln1_w, (const bf16*)qkv, \
+                                                                               (const bf16*)o, lse, (const bf16*)woT, (const bf16*)wqkvT, eps, n,     \
+                                                                               (bf16*)dqkv, (R*)dx_out, (bf16*)dxt_out, ln_part)
+    if (m3l_call_rb()) { if (D == 128) ABB_LAUNCH(2, bf16); else ABB_LAUNCH(3, bf16); }
+    else if (D == 128) ABB_LAUNCH(2, float);
+    else ABB_LAUNCH(3, float);
 #undef ABB_LAUNCH
     M3L_LAUNCH_CHECK();
     return 0;

@@ -50,7 +50,8 @@ struct MegaFwdPack {
     int count;
 };
 
-template <int KT>
+// R: storage type of the residual stream (the float* x / x1 / xout of the pack then point at bf16 data: m3l_set_residual_bf16)
+template <int KT, typename R>
 __global__ __launch_bounds__(AB_THREADS) void enc_fwd_mega_kernel(const float* __restrict__ x0, MegaFwdPack P, float eps, int n, int mlp,
                                                                     unsigned long long* __restrict__ phase_ts) {
     // (Odd workgroups started 8 - 40 K cycles late, so that the phases of neighbouring CUs interleave instead of running chip-wide in
@@ -61,10 +62,10 @@ __global__ __launch_bounds__(AB_THREADS) void enc_fwd_mega_kernel(const float* _
     for (int step = 0; step < 2 * P.count; ++step) {
         const MegaFwdLayer& L = P.L[step >> 1];
         if ((step & 1) == 0) {
-            attn_block_fwd_body<KT>(x, L.ln1_w, L.ln1_b, L.wqkv, L.wo, L.bo, L.ln2_w, L.ln2_b, eps, n, L.xn1, L.qkv, L.o, L.lse, L.x1, L.xn2,
-                                    step == 0 ? phase_ts : nullptr);
+            attn_block_fwd_body<KT, R>(reinterpret_cast<const R*>(x), L.ln1_w, L.ln1_b, L.wqkv, L.wo, L.bo, L.ln2_w, L.ln2_b, eps, n, L.xn1, L.qkv, L.o, L.lse,
+                                       reinterpret_cast<R*>(L.x1), L.xn2, step == 0 ? phase_ts : nullptr);
         } else {
-            mlp_block_fwd_body<KT>(L.xn2, L.x1, L.w1, L.b1, L.w2, L.b2, n, mlp, L.u, L.h, L.xout);
+            mlp_block_fwd_body<KT, R>(L.xn2, reinterpret_cast<const R*>(L.x1), L.w1, L.b1, L.w2, L.b2, n, mlp, L.u, L.h, reinterpret_cast<R*>(L.xout));
             x = L.xout;
         }
         __syncthreads();
@@ -104,14 +105,16 @@ struct MegaBwdPack {
     int count;
 };
 
-template <int KT>
+template <int KT, typename R>
 __global__ __launch_bounds__(AB_THREADS) void enc_bwd_mega_kernel(float* __restrict__ dx, MegaBwdPack P, float eps, int n, int mlp) {
     for (int step = 0; step < 2 * P.count; ++step) {
         const MegaBwdLayer& L = P.L[step >> 1];
         if ((step & 1) == 0)
-            mlp_block_bwd_body<KT>(L.dxt, dx, L.x1, L.ln2_w, L.u, L.w2T, L.w1T, eps, n, mlp, L.du, L.dx1t, L.cs_part, L.ln2_part);
+            mlp_block_bwd_body<KT, R>(L.dxt, reinterpret_cast<R*>(dx), reinterpret_cast<const R*>(L.x1), L.ln2_w, L.u, L.w2T, L.w1T, eps, n, mlp, L.du, L.dx1t,
+                                      L.cs_part, L.ln2_part);
         else
-            attn_block_bwd_body<KT>(L.dx1t, dx, L.x, L.ln1_w, L.qkv, L.o, L.lse, L.woT, L.wqkvT, eps, n, L.dqkv, L.dx_out, L.dxt_out, L.ln1_part);
+            attn_block_bwd_body<KT, R>(L.dx1t, reinterpret_cast<const R*>(dx), reinterpret_cast<const R*>(L.x), L.ln1_w, L.qkv, L.o, L.lse, L.woT, L.wqkvT, eps, n,
+                                       L.dqkv, reinterpret_cast<R*>(L.dx_out), L.dxt_out, L.ln1_part);
         __syncthreads();
     }
 }
@@ -140,8 +143,10 @@ extern "C" int m3l_set_enc_mega(int mode) {
 int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* const* layers, int count, float eps, hipStream_t st) {
     static int inited_mlp = 0;
     if (inited_mlp != mlp) {
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<2>(mlp)));
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<3>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<2>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<3>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<2, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<2>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_fwd_mega_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_fwd_lds<3>(mlp)));
         inited_mlp = mlp;
     }
     M3L_CHECK(D == 128 || D == 192, "enc_fwd_mega: D=%d unsupported", D);
@@ -151,10 +156,13 @@ int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* 
     memcpy(P.L, layers, (size_t)count * sizeof(MegaFwdLayer));
     P.count = count;
     ProfScope prof("enc_fwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st);
-    if (D == 128)
-        enc_fwd_mega_kernel<2><<<B, AB_THREADS, mega_fwd_lds<2>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+    if (m3l_call_rb()) {
+        if (D == 128) enc_fwd_mega_kernel<2, bf16><<<B, AB_THREADS, mega_fwd_lds<2>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+        else enc_fwd_mega_kernel<3, bf16><<<B, AB_THREADS, mega_fwd_lds<3>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+    } else if (D == 128)
+        enc_fwd_mega_kernel<2, float><<<B, AB_THREADS, mega_fwd_lds<2>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
     else
-        enc_fwd_mega_kernel<3><<<B, AB_THREADS, mega_fwd_lds<3>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
+        enc_fwd_mega_kernel<3, float><<<B, AB_THREADS, mega_fwd_lds<3>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -167,9 +175,10 @@ int m3l_enc_bwd_mega(int D, int mlp, int B, int n, float* dx, const void* const*
     M3L_CHECK(count >= 1 && count <= M3L_MEGA_BWD_MAX_LAYERS, "enc_bwd_mega: %d layers (max %d)", count, M3L_MEGA_BWD_MAX_LAYERS);
     const int lds = D == 128 ? mega_bwd_lds<2>(mlp) : mega_bwd_lds<3>(mlp);
     M3L_CHECK(lds <= 160 * 1024, "enc_bwd_mega: mlp=%d needs %d bytes of LDS", mlp, lds);
+    M3L_CHECK(!m3l_call_rb(), "enc_bwd_mega: the grouped backward launch does not run the bf16 residual mode (per-half-layer launches do)");
     if (inited_mlp != mlp) {
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<2>(mlp)));
-        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<3>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<2>(mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)enc_bwd_mega_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, mega_bwd_lds<3>(mlp)));
         inited_mlp = mlp;
     }
     static_assert(sizeof(MegaBwdLayer) == 21 * sizeof(void*), "MegaBwdLayer is 21 pointers");
@@ -178,9 +187,9 @@ int m3l_enc_bwd_mega(int D, int mlp, int B, int n, float* dx, const void* const*
     P.count = count;
     ProfScope prof("enc_bwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st);
     if (D == 128)
-        enc_bwd_mega_kernel<2><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
+        enc_bwd_mega_kernel<2, float><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
     else
-        enc_bwd_mega_kernel<3><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
+        enc_bwd_mega_kernel<3, float><<<B, AB_THREADS, lds, st>>>(dx, P, eps, n, mlp);
     M3L_LAUNCH_CHECK();
     return 0;
 }

@@ -148,14 +148,14 @@ inline bool drop_h() {
     if (g_drop_h < 0) g_drop_h = getenv("M3L_DROP_H") ? (atoi(getenv("M3L_DROP_H")) > 0 ? 1 : 0) : 0;
     return g_drop_h == 1;
 }
-// bf16 residual stream (round 4, opt-in: env M3L_RES_BF16 / m3l_set_residual_bf16): x, x1, xout of every layer of a stack and its running
+// bf16 residual stream (round 4; default ON, env M3L_RES_BF16=0 / m3l_set_residual_bf16(0) restore fp32): x, x1, xout of every layer of a stack and its running
 // residual gradient travel through HBM as bf16 instead of fp32 (fp32 in registers: the arithmetic is unchanged, each half layer's result is
 // rounded once).  The tails of the fused kernels move mostly residual-type data at ~5.5 TB/s, so halving it is direct time; the residual
 // gradient needs no separate copy at all (the compute-type copy the GEMMs read IS it).  A stack runs in this mode when every layer takes
 // kernels that support it; its input and its input gradient stay fp32 at the interface (one cast each).
 int g_res_bf16 = -1;
 inline bool res_bf16_mode() {
-    if (g_res_bf16 < 0) g_res_bf16 = getenv("M3L_RES_BF16") ? (atoi(getenv("M3L_RES_BF16")) > 0 ? 1 : 0) : 0;
+    if (g_res_bf16 < 0) g_res_bf16 = getenv("M3L_RES_BF16") ? (atoi(getenv("M3L_RES_BF16")) > 0 ? 1 : 0) : 1;
     return g_res_bf16 == 1;
 }
 struct RbScope {          // residual mode of the launches issued inside the scope (read by the launchers: m3l_call_rb)
@@ -165,10 +165,13 @@ struct RbScope {          // residual mode of the launches issued inside the sco
 bool tf_rb(const m3l_tf_cfg* c, int B, int n, bool fuse) {
     if (!res_bf16_mode() || c->dtype != 1 || fuse || !c->project_out || c->depth < 1) return false;
     const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim;
+    // short sequences: the per-sample block kernels, forward and backward (the MAE encoder)
+    if (m3l_attn_block_supported(1, D, c->heads, n, c->project_out))
+        return m3l_mlp_block_supported(1, D, mlp, n) && m3l_mlp_block_bwd_supported(1, D, mlp, n) && m3l_attn_block_bwd_enabled() &&
+               !(m3l_mlp_t192_short() && m3l_mlp_t192_supported(1, D, mlp, M)) && !(m3l_enc_mega_enabled() & 2);
     // long sequences: per-sample attention + row-tiled feed-forward kernels, forward and backward (the MAE decoder)
     return m3l_attn_t192_fwd_supported(1, D, c->heads, n, B) && m3l_attn_tail_mlp_t192_supported(1, D, HD, mlp, M) &&
-           !m3l_attn_block_supported(1, D, c->heads, n, c->project_out) && !m3l_mlp_block_bwd_supported(1, D, mlp, n) &&
-           m3l_qkv_bwd_t192_supported(1, D, 3 * HD, M);
+           !m3l_mlp_block_bwd_supported(1, D, mlp, n) && m3l_qkv_bwd_t192_supported(1, D, 3 * HD, M);
 }
 
 // which fused kernel (if any) computes the feed-forward half of a layer in the FORWARD — the same decisions as m3l_transformer_fwd below:
@@ -895,7 +898,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         if (mlp_block) {
             // short sequences: du, its column sums, dxn2 and the LN2 backward in one launch; one partial row per sample
             cs_rows = B;
-            if (m3l_mlp_block_bwd(D, mlp, B, n, w.dx_t[cur], w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
+            if (m3l_mlp_block_bwd(D, mlp, B, n, w.dx_t[cur], rb ? nullptr : w.dx, L.x1, (const float*)t[5], L.u, L.w2T, L.w1T, LN_EPS, w.du[cur], w.dx1_t[cur],
                                   w.scratch2[cur], ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr, B), st))
                 return 1;
         } else if (mlp_t192) {
@@ -934,8 +937,13 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             // short sequences: dO, the attention backward, dxn1 and the LN1 backward in one launch.  It writes dx_t[nxt] (the next
             // layer's operand set)
             if (l && claim_set(nxt)) return 2;
-            if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
-                                   dx_dst, l ? w.dx_t[nxt] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+            if (rb) {      // the residual gradient is dx1_t itself; the result goes to the next layer's dx_t, or — layer 0 — through d_o to dx_in
+                if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], nullptr, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
+                                       nullptr, l ? w.dx_t[nxt] : w.d_o, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+                    return 1;
+                if (l == 0 && dx_in && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+            } else if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
+                                          dx_dst, l ? w.dx_t[nxt] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                 return 1;
         }
         const void* d_o = w.dx1_t[cur];

@@ -66,12 +66,12 @@ template <int KT> struct MbLayout {
     static_assert(KT == 2 || KT == 3, "vmcnt immediates in the DMA wave are 16 / 24");
 };
 
-template <int KT>
-__device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+template <int KT, typename R>
+__device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2, const R* __restrict__ x1,
                                                                      const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                      const bf16* __restrict__ W2, const float* __restrict__ b2, int n,
                                                                      int mlp, bf16* __restrict__ u_out, bf16* __restrict__ h_out,
-                                                                     float* __restrict__ xout) {
+                                                                     R* __restrict__ xout) {
     using Ly = MbLayout<KT>;
     constexpr int D = Ly::D, KSTEPS = 2 * KT;
     constexpr int NDMA = 8 * KT;
@@ -163,7 +163,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
         for (int c = 0; c < KT; ++c) {
             const int col = 4 * (li + 16 * c);
             b2r[c] = *reinterpret_cast<const f32x4*>(b2 + col);
-            x1r[c] = r < n ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            x1r[c] = r < n ? ld_res4<R>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const int ct = wave & 3, rt = wave >> 2;
@@ -295,7 +295,7 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
             for (int c = 0; c < KT; ++c) {
                 const int col = 4 * (li + 16 * c);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(Y + r * YLD + col) + b2r[c] + x1r[c];
-                *reinterpret_cast<f32x4*>(xout + (row0 + r) * D + col) = v;
+                st_res4<R>(xout + (row0 + r) * D + col, v);
             }
         }
     }
@@ -309,9 +309,11 @@ __device__ M3L_BODY_INLINE void mlp_block_fwd_body(const bf16* __restrict__ xn2,
 //     dx1  = dx + LN2-backward(dxn2; x1, gamma2)      in place, + compute-type copy, + [3 D] partials (dgamma2 | dbeta2 | colsum dx1)
 // Same ring / barrier structure as the forward with (W2^T, W1^T) in place of (W1, W2): block 2c = rows 64c.. of W2^T [mlp][D],
 // block 2c + 1 = columns 64c.. of W1^T [D][mlp].  The DMA wave brings chunk c of u with block 2c.
-template <int KT>
-__device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt, float* __restrict__ dx,
-                                                                     const float* __restrict__ x1, const float* __restrict__ ln2_w,
+// R = storage type of the residual stream (dx, x1).  bf16: the incoming residual gradient is read from dxt (it IS that gradient) and only
+// the compute-type result dx1t_out is written
+template <int KT, typename R>
+__device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt, R* __restrict__ dx,
+                                                                     const R* __restrict__ x1, const float* __restrict__ ln2_w,
                                                                      const bf16* __restrict__ u, const bf16* __restrict__ W2T,
                                                                      const bf16* __restrict__ W1T, float eps, int n, int mlp,
                                                                      bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
@@ -412,8 +414,9 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
         for (int c = 0; c < KT; ++c) {
             const int col = 4 * (li + 16 * c);
             gmr[c] = *reinterpret_cast<const f32x4*>(ln2_w + col);
-            x1r[c] = r < n ? *reinterpret_cast<const f32x4*>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            dxr[c] = r < n ? *reinterpret_cast<const f32x4*>(dx + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            x1r[c] = r < n ? ld_res4<R>(x1 + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (sizeof(R) == 2) dxr[c] = r < n ? ld_res4<bf16>(dxt + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else dxr[c] = r < n ? ld_res4<R>(dx + (row0 + r) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const int ct = wave & 3, rt = wave >> 2;
@@ -533,7 +536,7 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
             f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 rr = (gd[c] - s1 - xh[c] * s2) * rstd + dxr[c];
-                *reinterpret_cast<f32x4*>(dx + (row0 + r) * D + col) = rr;
+                if (sizeof(R) == 4) st_res4<R>(dx + (row0 + r) * D + col, rr);
                 bf16x4 pk;
                 pk[0] = (bf16)rr[0]; pk[1] = (bf16)rr[1]; pk[2] = (bf16)rr[2]; pk[3] = (bf16)rr[3];
                 *reinterpret_cast<bf16x4*>(dx1t_out + (row0 + r) * D + col) = pk;
@@ -563,22 +566,22 @@ __device__ M3L_BODY_INLINE void mlp_block_bwd_body(const bf16* __restrict__ dxt,
 }
 
 #ifndef M3L_BLOCK_BODIES_ONLY
-template <int KT>
-__global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* __restrict__ xn2, const float* __restrict__ x1,
+template <int KT, typename R>
+__global__ __launch_bounds__(MB_THREADS) void mlp_block_fwd_kernel(const bf16* __restrict__ xn2, const R* __restrict__ x1,
                                                                      const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                      const bf16* __restrict__ W2, const float* __restrict__ b2, int n,
                                                                      int mlp, bf16* __restrict__ u_out, bf16* __restrict__ h_out,
-                                                                     float* __restrict__ xout) {
-    mlp_block_fwd_body<KT>(xn2, x1, W1, b1, W2, b2, n, mlp, u_out, h_out, xout);
+                                                                     R* __restrict__ xout) {
+    mlp_block_fwd_body<KT, R>(xn2, x1, W1, b1, W2, b2, n, mlp, u_out, h_out, xout);
 }
-template <int KT>
-__global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* __restrict__ dxt, float* __restrict__ dx,
-                                                                     const float* __restrict__ x1, const float* __restrict__ ln2_w,
+template <int KT, typename R>
+__global__ __launch_bounds__(MB_THREADS) void mlp_block_bwd_kernel(const bf16* __restrict__ dxt, R* __restrict__ dx,
+                                                                     const R* __restrict__ x1, const float* __restrict__ ln2_w,
                                                                      const bf16* __restrict__ u, const bf16* __restrict__ W2T,
                                                                      const bf16* __restrict__ W1T, float eps, int n, int mlp,
                                                                      bf16* __restrict__ du_out, bf16* __restrict__ dx1t_out,
                                                                      float* __restrict__ cs_part, float* __restrict__ ln_part) {
-    mlp_block_bwd_body<KT>(dxt, dx, x1, ln2_w, u, W2T, W1T, eps, n, mlp, du_out, dx1t_out, cs_part, ln_part);
+    mlp_block_bwd_body<KT, R>(dxt, dx, x1, ln2_w, u, W2T, W1T, eps, n, mlp, du_out, dx1t_out, cs_part, ln_part);
 }
 #endif
 
@@ -605,17 +608,21 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
     M3L_CHECK(D == 128 || D == 192, "mlp_block_bwd: D=%d unsupported", D);
     const size_t lds = mb_bwd_lds(D / 64, mlp);
     if (inited_mlp != mlp) {
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(2, mlp)));
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(3, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(3, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<2, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(3, mlp)));
         inited_mlp = mlp;
     }
     ProfScope prof("mlp_block_bwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
-    if (D == 128)
-        mlp_block_bwd_kernel<2><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T,
-                                                           eps, n, mlp, (bf16*)du, (bf16*)dx1t, cs_part, ln_part);
-    else
-        mlp_block_bwd_kernel<3><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, dx, x1, ln2_w, (const bf16*)u, (const bf16*)w2T, (const bf16*)w1T,
-                                                           eps, n, mlp, (bf16*)du, (bf16*)dx1t, cs_part, ln_part);
+    // (m3l_call_rb(): the residual stream of this launch — x1; dx is then unused — is bf16)
+#define MBB_LAUNCH(KT, R)                                                                                                                  \
+    mlp_block_bwd_kernel<KT, R><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, (R*)dx, (const R*)x1, ln2_w, (const bf16*)u, (const bf16*)w2T,     \
+                                                           (const bf16*)w1T, eps, n, mlp, (bf16*)du, (bf16*)dx1t, cs_part, ln_part)
+    if (m3l_call_rb()) { if (D == 128) MBB_LAUNCH(2, bf16); else MBB_LAUNCH(3, bf16); }
+    else if (D == 128) MBB_LAUNCH(2, float);
+    else MBB_LAUNCH(3, float);
+#undef MBB_LAUNCH
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -627,17 +634,20 @@ int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float
                       const float* b2, void* u, void* h, float* xout, hipStream_t st) {
     static int inited_mlp = 0;
     if (inited_mlp != mlp) {
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(2, mlp)));
-        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(3, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(3, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<2, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(2, mlp)));
+        M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_fwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_fwd_lds(3, mlp)));
         inited_mlp = mlp;
     }
     M3L_CHECK(D == 128 || D == 192, "mlp_block: D=%d unsupported", D);
     ProfScope prof("mlp_block_fwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
-#define MB_LAUNCH(KT)                                                                                                                  \
-    mlp_block_fwd_kernel<KT><<<B, MB_THREADS, mb_fwd_lds(KT, mlp), st>>>((const bf16*)xn2, x1, (const bf16*)w1, b1, (const bf16*)w2, b2, n, \
-                                                                        mlp, (bf16*)u, (bf16*)h, xout)
-    if (D == 128) MB_LAUNCH(2);
-    else MB_LAUNCH(3);
+#define MB_LAUNCH(KT, R)                                                                                                                  \
+    mlp_block_fwd_kernel<KT, R><<<B, MB_THREADS, mb_fwd_lds(KT, mlp), st>>>((const bf16*)xn2, (const R*)x1, (const bf16*)w1, b1, (const bf16*)w2, b2, n, \
+                                                                           mlp, (bf16*)u, (bf16*)h, (R*)xout)
+    if (m3l_call_rb()) { if (D == 128) MB_LAUNCH(2, bf16); else MB_LAUNCH(3, bf16); }
+    else if (D == 128) MB_LAUNCH(2, float);
+    else MB_LAUNCH(3, float);
 #undef MB_LAUNCH
     M3L_LAUNCH_CHECK();
     return 0;

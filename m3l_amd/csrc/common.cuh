@@ -255,6 +255,10 @@ template <typename R> __device__ __forceinline__ f32x4 round_res(f32x4 v) {
 // residual-stream mode of the launch being issued (set by the transformer plan around its kernels; 0 = fp32, 1 = bf16)
 int m3l_call_rb(void);
 void m3l_set_call_rb(int rb);
+// 1: the stack input / input gradient handed to m3l_transformer_fwd / _bwd, the un-shuffle's output and its backward's input are bf16 too
+// (the fused step sets it around the decoder when that stack runs the bf16 residual stream: no boundary casts)
+int m3l_call_io(void);
+void m3l_set_call_io(int on);
 void m3l_set_error(const char* fmt, ...);
 #define M3L_CHECK(cond, ...)                 \
     do {                                     \

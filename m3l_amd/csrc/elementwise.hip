@@ -972,12 +972,13 @@ __global__ __launch_bounds__(256) void embed_finalize_bwd_kernel(const float* __
 
 // ---------------------------------------------------------------------------------------------------------------
 // decoder un-shuffle (pretrain_models.py:279-307): dec_in[b, pos] = (visible ? src[b, j] : mask_token) + dmod[m(pos)] + dpos[pos]
+template <typename TO>
 __global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float* __restrict__ src, const float* __restrict__ mask_token,
                                                               const int64_t* __restrict__ unmasked, int nvis,
                                                               const int64_t* __restrict__ masked, int nmask, int B, int dd,
                                                               int n_img, int n_tac, const float* __restrict__ dmod,
                                                               const float* __restrict__ pos_img, const float* __restrict__ pos_tac,
-                                                              float* __restrict__ dec_in) {
+                                                              TO* __restrict__ dec_in) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int N = nvis + nmask;
@@ -988,8 +989,9 @@ __global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float* __restr
     const float* s = vis ? src + ((long)b * nvis + j) * dd : mask_token;
     const int m = pos < n_img ? 0 : 1 + (pos - n_img) / n_tac;
     const float* prow = pos < n_img ? pos_img + (long)pos * dd : pos_tac + (long)(pos - n_img) * dd;
-    float* out = dec_in + ((long)b * N + pos) * dd;
-    for (int e = lane; e < dd; e += 64) out[e] = s[e] + dmod[(long)m * dd + e] + prow[e];
+    TO* out = dec_in + ((long)b * N + pos) * dd;
+    const float* mrow = dmod + (long)m * dd;
+    for (int e = 4 * lane; e < dd; e += 256) store4<TO>(out + e, load4(s + e) + load4(mrow + e) + load4(prow + e));      // (dd % 4 == 0)
 }
 
 // backward of the decoder-input assembly: dsrc[b, j] = dY[b, unmasked[b, j]] ; partials [G][(1 + nmod) * dd]: dmask_token | ddmod[m].
@@ -998,8 +1000,8 @@ __global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float* __restr
 //   dmask_token = (sum over all rows) - (sum over the visible rows).
 // A wave walks a contiguous run of rows with 16-byte loads and keeps running column sums in registers, flushed into its private LDS
 // slab when the modality changes (at most nmod + 1 times per sample); a second loop gathers its share of the visible rows.
-template <int MAXC>
-__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ dY, const int64_t* __restrict__ unmasked, int nvis,
+template <int MAXC, typename TI>
+__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const TI* __restrict__ dY, const int64_t* __restrict__ unmasked, int nvis,
                                                               int B, int N, int dd, int n_img, int n_tac, int nmod, int rows_per_wave,
                                                               int vis_per_wave, float* __restrict__ dsrc, float* __restrict__ part) {
     extern __shared__ float sm[];   // [WPB][(1 + nmod) * dd]: one private slab per wave
@@ -1036,11 +1038,8 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
             for (int c = 0; c < MAXC; ++c) {
                 const int e4 = (lane + 64 * c) * 4;
                 if (e4 < dd) {
-                    const float* g = dY + r * dd + e4;
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(g);
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(g + dd);
-                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(g + 2 * dd);
-                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(g + 3 * dd);
+                    const TI* g = dY + r * dd + e4;
+                    const f32x4 d0 = load4(g), d1 = load4(g + dd), d2 = load4(g + 2 * dd), d3 = load4(g + 3 * dd);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[c][q] += (d0[q] + d1[q]) + (d2[q] + d3[q]);
                 }
@@ -1051,7 +1050,7 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
             for (int c = 0; c < MAXC; ++c) {
                 const int e4 = (lane + 64 * c) * 4;
                 if (e4 < dd) {
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(dY + r * dd + e4);
+                    const f32x4 d = load4(dY + r * dd + e4);
                     acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
                 }
             }
@@ -1063,7 +1062,7 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
     const long v0 = gw * vis_per_wave, v1 = v0 + vis_per_wave < vtotal ? v0 + vis_per_wave : vtotal;
     long v = v0;
     for (; v + 4 <= v1; v += 4) {
-        const float* g[4];
+        const TI* g[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) g[u] = dY + ((long)((v + u) / nvis) * N + (int)unmasked[v + u]) * dd;
 #pragma unroll
@@ -1072,7 +1071,7 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
             if (e4 < dd) {
                 f32x4 d[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) d[u] = *reinterpret_cast<const f32x4*>(g[u] + e4);
+                for (int u = 0; u < 4; ++u) d[u] = load4(g[u] + e4);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dsrc + (v + u) * dd + e4) = d[u];
 #pragma unroll
@@ -1083,12 +1082,12 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
     for (; v < v1; ++v) {
         const int b = (int)(v / nvis);
         const int pos = (int)unmasked[v];
-        const float* g = dY + ((long)b * N + pos) * dd;
+        const TI* g = dY + ((long)b * N + pos) * dd;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int e4 = (lane + 64 * c) * 4;
             if (e4 < dd) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(g + e4);
+                const f32x4 d = load4(g + e4);
                 *reinterpret_cast<f32x4*>(dsrc + v * dd + e4) = d;
                 acc[c][0] += d[0]; acc[c][1] += d[1]; acc[c][2] += d[2]; acc[c][3] += d[3];
             }
@@ -1645,8 +1644,13 @@ int k_unshuffle_fwd(const float* src, const float* mask_token, const int64_t* un
                       int nmask, int B, int dd, int n_img, int n_tac, const float* dmod, const float* pos_img, const float* pos_tac,
                       float* dec_in, hipStream_t st) {
     const long rows = (long)B * (nvis + nmask);
-    unshuffle_fwd_kernel<<<cdiv(rows, WPB), 256, 0, st>>>(src, mask_token, unmasked, nvis, masked, nmask, B, dd, n_img,
-                                                           n_tac > 0 ? n_tac : 1, dmod, pos_img, pos_tac, dec_in);
+    M3L_CHECK(dd % 4 == 0, "unshuffle_fwd: dd=%d must be a multiple of 4", dd);
+    if (m3l_call_io())      // the decoder runs the bf16 residual stream and takes its input as bf16 (fused step)
+        unshuffle_fwd_kernel<bf16><<<cdiv(rows, WPB), 256, 0, st>>>(src, mask_token, unmasked, nvis, masked, nmask, B, dd, n_img, n_tac > 0 ? n_tac : 1, dmod,
+                                                                     pos_img, pos_tac, reinterpret_cast<bf16*>(dec_in));
+    else
+        unshuffle_fwd_kernel<float><<<cdiv(rows, WPB), 256, 0, st>>>(src, mask_token, unmasked, nvis, masked, nmask, B, dd, n_img, n_tac > 0 ? n_tac : 1, dmod,
+                                                                      pos_img, pos_tac, dec_in);
     M3L_LAUNCH_CHECK();
     return 0;
 }
@@ -1664,12 +1668,13 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
     const int vpw = cdiv((long)B * nvis, (long)G * WPB);
     const int N = nvis + nmask, nt = n_tac > 0 ? n_tac : 1;
     const size_t lds = WPB * PL * sizeof(float);
-    if (dd <= 256)
-        unshuffle_bwd_kernel<1><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
-    else if (dd <= 512)
-        unshuffle_bwd_kernel<2><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
-    else
-        unshuffle_bwd_kernel<4><<<G, 256, lds, st>>>(dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws);
+#define UNSH_BWD(C, TI) unshuffle_bwd_kernel<C, TI><<<G, 256, lds, st>>>((const TI*)dY, unmasked, nvis, B, N, dd, n_img, nt, nmod, rpw, vpw, dsrc, part_ws)
+    if (m3l_call_io()) {      // the gradient of the decoder's input arrives as bf16 (fused step, bf16 residual stream)
+        if (dd <= 256) UNSH_BWD(1, bf16); else if (dd <= 512) UNSH_BWD(2, bf16); else UNSH_BWD(4, bf16);
+    } else {
+        if (dd <= 256) UNSH_BWD(1, float); else if (dd <= 512) UNSH_BWD(2, float); else UNSH_BWD(4, float);
+    }
+#undef UNSH_BWD
     M3L_LAUNCH_CHECK();
     if (nmod <= 3) {                                            // mask token + every modality row: equal-width segments, one launch
         ReduceSegs segs = {{dmask_token, ddmod, nmod > 1 ? ddmod + dd : nullptr, nmod > 2 ? ddmod + 2 * dd : nullptr}};

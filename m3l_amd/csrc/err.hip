@@ -27,3 +27,9 @@ extern "C" int m3l_last_error(char* buf, size_t n) {
 static thread_local int g_call_rb = 0;
 int m3l_call_rb(void) { return g_call_rb; }
 void m3l_set_call_rb(int rb) { g_call_rb = rb ? 1 : 0; }
+
+// the tensors a stack exchanges with its neighbours in the fused step (decoder input written by the un-shuffle, its gradient read by the
+// un-shuffle backward) are bf16 as well: set by mae_step.hip around the calls concerned when that stack runs the bf16 residual stream
+static thread_local int g_call_io = 0;
+int m3l_call_io(void) { return g_call_io; }
+void m3l_set_call_io(int on) { g_call_io = on ? 1 : 0; }

@@ -202,6 +202,8 @@ int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, f
 int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
 int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
+struct m3l_tf_cfg;
+extern "C" int m3l_transformer_rb(const m3l_tf_cfg* c, int B, int n);       // 1: the stack runs the bf16 residual stream at this shape
 int m3l_cast_bf16_f32(const void* x, long count, float* out, hipStream_t st);                               // out = (float)x
 int m3l_scale_by_dev(int dtype, const void* x, long count, const float* scale_dev, void* out, hipStream_t st);  // out = x * *scale
 int m3l_mask_scale(int mode, const float* src, const void* ref, float scale, long count, float* out, hipStream_t st);

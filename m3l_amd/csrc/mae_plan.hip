@@ -420,6 +420,12 @@ int m3l_side_pending(void) {
     return (int)g_pending.size();
 }
 
+// 1 when this stack runs the bf16 residual stream at (B, n) (mae_step.hip: whether its neighbours exchange bf16 with it)
+int m3l_transformer_rb(const m3l_tf_cfg* c, int B, int n) {
+    const int D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim;
+    return tf_rb(c, B, n, use_rowln() && m3l_gemm_nt_rowln_supported(c->dtype, D, HD) && m3l_gemm_nt_rowln_supported(c->dtype, D, mlp)) ? 1 : 0;
+}
+
 int m3l_set_residual_bf16(int on) {
     const int old = res_bf16_mode() ? 1 : 0;
     g_res_bf16 = on ? 1 : 0;
@@ -632,7 +638,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     // bf16 residual stream: the stack's input as bf16 (kept for the backward of layer 0 in the otherwise unused dxn buffer); from here on
     // every `float*` of the residual stream points at bf16 data and the launchers are told so
     const bool rb = tf_rb(c, B, n, fuse);
-    if (rb) {
+    if (rb && !m3l_call_io()) {          // (m3l_call_io: the caller hands x_in over as bf16 already)
         if (m3l_cast_f32(1, x_in, (long)M * D, w.dxn, st)) return 1;
         x = reinterpret_cast<const float*>(w.dxn);
     }
@@ -886,7 +892,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         TfLayer& L = w.L[l];
         const int cur = l % NS, nxt = l ? (l - 1) % NS : 0;
-        const float* xl = l ? w.L[l - 1].xout : (rb ? reinterpret_cast<const float*>(w.dxn) : x_in);
+        const float* xl = l ? w.L[l - 1].xout : ((rb && !m3l_call_io()) ? reinterpret_cast<const float*>(w.dxn) : x_in);
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
         // set `cur` (dx_t[cur] was written by layer l+1's last kernel, which claimed the set) receives du / dx1_t / dqkv of this layer
@@ -938,10 +944,11 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             // layer's operand set)
             if (l && claim_set(nxt)) return 2;
             if (rb) {      // the residual gradient is dx1_t itself; the result goes to the next layer's dx_t, or — layer 0 — through d_o to dx_in
+                const bool io = m3l_call_io() && dx_in;
                 if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], nullptr, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
-                                       nullptr, l ? w.dx_t[nxt] : w.d_o, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+                                       nullptr, l ? w.dx_t[nxt] : (io ? (void*)dx_in : w.d_o), ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                     return 1;
-                if (l == 0 && dx_in && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
             } else if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
                                           dx_dst, l ? w.dx_t[nxt] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                 return 1;
@@ -993,11 +1000,12 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             if (rb) {
                 // dres = dx1_t of this layer (bf16), result only in the compute type: the next layer's dx_t, or — layer 0 — a bf16 scratch
                 // (d_o, unused on this path) that is cast to the fp32 gradient of the stack's input
-                void* out_t = l ? w.dx_t[nxt] : w.d_o;
+                const bool io = m3l_call_io() && dx_in;           // the caller takes the input gradient as bf16: no cast
+                void* out_t = l ? w.dx_t[nxt] : (io ? (void*)dx_in : w.d_o);
                 if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, reinterpret_cast<const float*>(w.dx1_t[cur]), LN_EPS,
                                      nullptr, out_t, ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                     return 1;
-                if (l == 0 && dx_in && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
             } else if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
                                         ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                 return 1;

@@ -57,6 +57,11 @@ __global__ void mean_tokens_bwd_kernel(const float* __restrict__ dout, int n, in
     if (i < (long)n * D) dy[(long)b * n * D + i] = dout[(long)b * D + (i % D)] / (float)n;
 }
 
+struct IoScope {          // m3l_call_io for the calls inside the scope
+    explicit IoScope(bool on) { m3l_set_call_io(on ? 1 : 0); }
+    ~IoScope() { m3l_set_call_io(0); }
+};
+
 struct StepDims {
     int n_img, n_tac, k, N, nmask, nvis, nm_img, nm_tac, nvis_img;
     int D, dd, dt;
@@ -247,12 +252,15 @@ int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const floa
     if (front_fwd(c, d, w.f, B, d.nvis, d.nvis_img, unmasked, image, tactiles, tensors + g.embed, w.tokens, st)) return 1;
     // encoder (:266)
     if (m3l_transformer_fwd(&c->enc, B, d.nvis, w.tokens, tensors + g.enc, w.ws_enc, w.enc_t, w.enc32, st)) return 1;
-    // enc_to_dec + un-shuffle + decoder positions (:270-307); f32 compute: the "compute-type" encoder output is the f32 one
+    // enc_to_dec + un-shuffle + decoder positions (:270-307); f32 compute: the "compute-type" encoder output is the f32 one.  When the
+    // decoder runs the bf16 residual stream, its input (and, in the backward, the gradient of it) is exchanged as bf16: no boundary casts
+    const IoScope dec_io(m3l_transformer_rb(&c->dec, B, d.N) && !c->learned_pos);      // (the same rule as the backward's)
     if (m3l_unshuffle_fwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, unmasked, masked, w.enc32, d.dt ? w.enc_t : (void*)w.enc32,
                           tensors + g.glue, w.ws_glue, w.dec_in, st))
         return 1;
     // decoder (:309)
     if (m3l_transformer_fwd(&c->dec, B, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.dec_t, w.dec32, st)) return 1;
+    m3l_set_call_io(0);
     // heads + masked MSE (:260-262,327-340); early conv: every patch is predicted and scored (:311-322)
     const int64_t* rows = masked;
     int nrows = d.nmask, nrows_img = d.nm_img;
@@ -314,11 +322,15 @@ int m3l_mae_step_bwd(const m3l_mae_cfg* c, int B, const float* image, const floa
                            grads + g.heads, st))
         return 1;
     if (stage_done()) return 1;
-    if (tf_bwd(&c->dec, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.d_dec, d.dt, w.d_dec_in, grads + g.dec)) return 1;
+    const bool dec_io = m3l_transformer_rb(&c->dec, B, d.N) && !c->learned_pos;     // (the batch sums of learned positions read fp32 d_dec_in)
     int enc_code = 0;
-    if (m3l_unshuffle_bwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, unmasked, masked, d.dt ? w.enc_t : (void*)w.enc32,
-                          tensors + g.glue, w.ws_glue, w.d_dec_in, w.d_enc, &enc_code, grads + g.glue, st))
-        return 1;
+    {
+        const IoScope io(dec_io);
+        if (tf_bwd(&c->dec, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.d_dec, d.dt, w.d_dec_in, grads + g.dec)) return 1;
+        if (m3l_unshuffle_bwd(&c->geom, d.D, d.dd, d.dt, B, d.nvis, d.nmask, unmasked, masked, d.dt ? w.enc_t : (void*)w.enc32,
+                              tensors + g.glue, w.ws_glue, w.d_dec_in, w.d_enc, &enc_code, grads + g.glue, st))
+            return 1;
+    }
     if (c->learned_pos) {        // decoder_pos_emb rows (:280-287): every position is present in the decoder input -> plain batch sums
         float* const* gg = grads + g.glue;
         const int stride = d.N * d.dd;

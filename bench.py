@@ -479,7 +479,7 @@ def main():
             raw_us = ms_tot / launches * 1e3
             avg_s = max(raw_us - ev_overhead_us, 0.1) * 1e-6       # bracket minus the empty-bracket cost = kernel time
             gbs = byt / launches / avg_s / 1e9
-            kfull = {"wgrad": "wgrad_kernel<3>", "gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname)
+            kfull = {"wgrad": "wgrad_kernel<6,3> (384x192 tiles; the grouped per-layer launches)", "gemm_nt_glds64": "gemm_nt_glds_kernel<bf16,64,2,*>"}.get(kname, kname)
             traffic = prof.get("wgrad_grouped" if kname == "wgrad" else kname, prof.get(kname, {})).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": kfull, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(gbs / 8000.0, 4), "traffic": traffic,

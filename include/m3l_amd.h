@@ -117,7 +117,7 @@ int m3l_set_t192_tt(int tt);
  * the stack's input and input gradient stay fp32 at this interface).  Set it before a forward and keep it until its backward has run.
  * Loss stays within the 1e-2 of bf16 compute; gradients carry one more bf16 rounding per half layer.  Returns the previous setting. */
 int m3l_set_residual_bf16(int on);
-/* experiment switch of the row-tiled feed-forward backward: phase-offset wave groups / static wave priority; 0, 0 = off */
+/* experiment switch of the row-tiled feed-forward backward (EXPERIMENTS 5.2): phase-offset wave groups / static wave priority; 0, 0 = off */
 int m3l_set_t192_stagger(int lead_mask, int prio_mask);
 
 /* ---- mask sampling (INT path, bit-exact): noise[i] is (B, n_i) f32, RNG order image, tactile1..k.

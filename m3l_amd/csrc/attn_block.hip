@@ -10,7 +10,7 @@
 //
 // Workgroup = 13 waves: 12 compute waves (3 per SIMD: with one workgroup per CU, that is all the latency hiding there is), wave 12
 // only issues LDS-DMA (a wave that also reads LDS or stores gets its vmcnt waits
-// drained by the compiler / by its own stores — see DESIGN.md 4b).  bf16 operands, fp32 accumulation and statistics.
+// drained by the compiler / by its own stores — see EXPERIMENTS.md 2).  bf16 operands, fp32 accumulation and statistics.
 // Supported: D = 64 KT (KT = 2, 3: LDS), heads = D / 64 (so to_out is a real projection with K = D), n <= 48 (3 row tiles).
 #include <hip/hip_runtime.h>
 #include <type_traits>

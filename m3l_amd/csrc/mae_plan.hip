@@ -364,7 +364,7 @@ int check_tf(const m3l_tf_cfg* c, int B, int n) {
 // =================================================================================================================
 extern "C" {
 
-int m3l_version(void) { return 300; }
+int m3l_version(void) { return 400; }
 
 // diagnostic switch (bench.py's stand-alone roofline figure, PMC passes): 1 = every weight gradient on the caller's stream
 int m3l_set_wgrad_inline(int on) {

@@ -21,10 +21,10 @@ if st:
     shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 
-# The weight-gradient kernel is launched in two populations: GROUPED launches (the four weights of 2-4 transformer layers: 640 workgroups
-# = 327 680 threads at cfg 2; the class bench.py brackets and prices in `roofline`) and single small Linears (patch embed / heads: <= 96
+# The weight-gradient kernel is launched in two populations: GROUPED launches (the four weights of 2-4 transformer layers: one workgroup
+# per CU x 768 threads = 196 608 threads at cfg 2; the class bench.py brackets and prices in `roofline`) and single small Linears (patch embed / heads: <= 96
 # workgroups).  They are kept apart by grid size so that counter bytes and algorithmic bytes describe the SAME launches.
-GROUPED_MIN_THREADS = 200000
+GROUPED_MIN_THREADS = 150000
 
 
 def collect(sub, counter, grid_min=0, grid_max=1 << 62):

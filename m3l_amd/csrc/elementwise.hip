@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
         for (int i = 0; i < MAXC; ++i) {
             const int ec = min(4 * (lane + 64 * i), D - 4);
             dyv[i] = load4(dyr + ec);
-            rs[i] = dres ? load4(dres + (long)row * D + ec) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (bf16 residual stream — TX is bf16 —: the residual gradient arrives in the compute type too)
+            rs[i] = dres ? load4(reinterpret_cast<const TX*>(dres) + (long)row * D + ec) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         float mean, rstd;
         row_stats<MAXC>(x + (long)row * D, D, lane, v, eps, mean, rstd);
@@ -1265,11 +1266,11 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
     const int G = m3l_ln_bwd_blocks(M);
     {
         ProfScope prof("ln_bwd", M, D, dy_dtype,
-                       (double)M * D * (4.0 + (dy_dtype ? 2 : 4) + (dres ? 4 : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
+                       (double)M * D * ((m3l_call_rb() ? 2.0 : 4.0) + (dy_dtype ? 2 : 4) + (dres ? (m3l_call_rb() ? 2 : 4) : 0) + (dx_out ? 4 : 0) + (dx_t_out ? (ct_dtype ? 2 : 4) : 0)), st);
 #define LN_BWD(TD, TC, C, TX) ln_bwd_kernel<TD, TC, C, TX><<<G, 256, 0, st>>>((const TD*)dy, (const TX*)x, M, D, gamma, eps, dres, dx_out, (TC*)dx_t_out, part_ws)
 #define LN_BWD_C(TD, TC, TX) { if (D <= 256) LN_BWD(TD, TC, 1, TX); else if (D <= 512) LN_BWD(TD, TC, 2, TX); else LN_BWD(TD, TC, 4, TX); }
-        if (m3l_call_rb()) {       // x is a bf16 residual stream (final LayerNorm of a stack): dres / dx_out are null, only dx_t_out is written
-            M3L_CHECK(!dres && !dx_out && dx_t_out && ct_dtype == 1, "ln_bwd: bf16 residual mode writes the compute-type gradient only");
+        if (m3l_call_rb()) {       // x is a bf16 residual stream: dres (if any) is bf16 as well, only dx_t_out is written
+            M3L_CHECK(!dx_out && dx_t_out && ct_dtype == 1, "ln_bwd: bf16 residual mode writes the compute-type gradient only");
             if (dy_dtype == 1) LN_BWD_C(bf16, bf16, bf16) else LN_BWD_C(float, bf16, bf16)
         }
         else if (dy_dtype == 1) LN_BWD_C(bf16, bf16, float)

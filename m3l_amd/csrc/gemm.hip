@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // combinations of the transformer get branch-free code the compiler can schedule across the unrolled row segments):
 //   1 FC1    bias + pre-activation copy + GELU -> out_t          2 DGELU  * gelu'(u) -> out_t (+ column-sum partials)
 //   3 PLAIN  (bias) -> out_t                                      4 RES32  bias + fp32 residual -> out_f32
-enum { EPI_GENERIC = 0, EPI_FC1 = 1, EPI_DGELU = 2, EPI_PLAIN = 3, EPI_RES32 = 4 };
+enum { EPI_GENERIC = 0, EPI_FC1 = 1, EPI_DGELU = 2, EPI_PLAIN = 3, EPI_RES32 = 4, EPI_RES16 = 5 };
 template <typename T, int BN, int R, int BM = 128, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              int M, int N, int K, GemmEpi epi) {
@@ -325,13 +325,14 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
     const bool f_out32 = GEN ? (epi.out_f32 != nullptr) : (EPI == EPI_RES32);
     const bool f_out_t = GEN ? (out_t != nullptr) : (EPI != EPI_RES32);
     const bool f_colsum = GEN ? (epi.colsum_part != nullptr) : (EPI == EPI_DGELU && epi.colsum_part != nullptr);
+    const bool f_res16 = sizeof(T) == 2 && (GEN ? (epi.res_t != nullptr) : (EPI == EPI_RES16));     // bf16 residual (shares ruu with gelu_u)
     // The epilogue's row operands (fp32 residual, pre-activation u) of ALL this thread's row segments are requested here, before the
     // accumulators' trip through LDS: loaded inside the store loop below, segment i's loads came behind segment i - 1's stores, and a
     // wave's vmcnt covers both kinds — every segment waited for the previous segment's HBM write as well as for its own read (four
     // dependent round trips per 128-row tile).  Rows past M read row M - 1 (dropped).
     f32x4 rq0[ITERS], rq1[ITERS];
     Frag<T> ruu[ITERS];
-    if (col_ok && (f_res || f_gelu_u)) {
+    if (col_ok && (f_res || f_gelu_u || f_res16)) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const long o = (long)min(m0 + r0 + RSTEP * i, M - 1) * epi.ldc + col;
@@ -346,6 +347,9 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ruu[i].v[j] = gelu_u[o + j];
                 }
+            }
+            if constexpr (sizeof(T) == 2) {
+                if (f_res16) ruu[i].v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(epi.res_t) + o);
             }
         }
     }
@@ -411,6 +415,10 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const T* __restrict__
                 const f32x4 q0 = rq0[i], q1 = rq1[i];
                 v[0] += q0[0]; v[1] += q0[1]; v[2] += q0[2]; v[3] += q0[3];
                 v[4] += q1[0]; v[5] += q1[1]; v[6] += q1[2]; v[7] += q1[3];
+            }
+            if (f_res16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += to_f32(ruu[i].v[j]);
             }
             if (f_out32) {
                 *reinterpret_cast<f32x4*>(epi.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -636,7 +644,7 @@ int m3l_gemm_init() {
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
 #define NT_ATTR(T, BMv, E) M3L_HIP(hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<T, 64, 2, BMv, E>, hipFuncAttributeMaxDynamicSharedMemorySize, glds_lds_bytes(64, 2, BMv)))
-#define NT_ATTR5(T, BMv) NT_ATTR(T, BMv, 0); NT_ATTR(T, BMv, 1); NT_ATTR(T, BMv, 2); NT_ATTR(T, BMv, 3); NT_ATTR(T, BMv, 4)
+#define NT_ATTR5(T, BMv) NT_ATTR(T, BMv, 0); NT_ATTR(T, BMv, 1); NT_ATTR(T, BMv, 2); NT_ATTR(T, BMv, 3); NT_ATTR(T, BMv, 4); NT_ATTR(T, BMv, 5)
     NT_ATTR5(bf16, 128); NT_ATTR5(float, 128); NT_ATTR5(bf16, 64); NT_ATTR5(float, 64);
 #undef NT_ATTR5
 #undef NT_ATTR
@@ -656,10 +664,12 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
     M3L_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && epi->ldc % 8 == 0,
               "gemm_nt: K,N,lda,ldw,ldc must be multiples of 8 (got K=%d N=%d lda=%d ldw=%d ldc=%d)", K, N, lda, ldw, epi->ldc);
     const int bke = dtype == 1 ? 64 : 32;
+    M3L_CHECK(!epi->res_t || (dtype == 1 && K % bke == 0 && epi->out_t && !epi->res && !epi->gelu_u),
+              "gemm_nt: a bf16 residual needs bf16 operands, K %% 64 == 0, a compute-type output, and neither an fp32 residual nor gelu_u");
     const double es = dtype ? 2.0 : 4.0;
     // algorithmic HBM bytes: A and W once, every epilogue operand / result once
     const double bytes = (double)M * K * es + (double)N * K * es +
-                         (double)M * N * ((epi->res ? 4.0 : 0.0) + (epi->out_f32 ? 4.0 : 0.0) + (epi->out_t ? es : 0.0) +
+                         (double)M * N * ((epi->res ? 4.0 : 0.0) + (epi->res_t ? 2.0 : 0.0) + (epi->out_f32 ? 4.0 : 0.0) + (epi->out_t ? es : 0.0) +
                                           (epi->out_pre ? es : 0.0) + (epi->gelu_u ? es : 0.0));
     const char* kind = (K % bke != 0) ? "gemm_nt_generic" : "gemm_nt_glds64";
     ProfScope prof(kind, M, N, K, 2.0 * M * N * K, st, bytes);
@@ -668,14 +678,16 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
         // tiles at 1-2 workgroups per CU); 64-row tiles when 128-row tiles would leave the chip under-filled
         const bool plain_alpha = epi->alpha == 1.0f && !epi->relu_ref;
         int mode = EPI_GENERIC;
-        if (plain_alpha && epi->out_t && epi->out_pre && epi->act == 1 && !epi->gelu_u && !epi->res && !epi->out_f32 && !epi->colsum_part)
+        if (plain_alpha && epi->out_t && epi->out_pre && epi->act == 1 && !epi->gelu_u && !epi->res && !epi->res_t && !epi->out_f32 && !epi->colsum_part)
             mode = EPI_FC1;
-        else if (plain_alpha && epi->out_t && epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->out_f32)
+        else if (plain_alpha && epi->out_t && epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->res_t && !epi->out_f32)
             mode = EPI_DGELU;
-        else if (plain_alpha && epi->out_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->out_f32 && !epi->colsum_part)
+        else if (plain_alpha && epi->out_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->res_t && !epi->out_f32 && !epi->colsum_part)
             mode = EPI_PLAIN;
         else if (plain_alpha && !epi->out_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && epi->res && epi->out_f32 && !epi->colsum_part)
             mode = EPI_RES32;
+        else if (plain_alpha && epi->out_t && epi->res_t && !epi->gelu_u && !epi->out_pre && epi->act == 0 && !epi->res && !epi->out_f32 && !epi->colsum_part)
+            mode = EPI_RES16;
         const bool small = nt_tile_rows(M, N) == 64;
         const dim3 grid(8 * cdiv(N, 64) * cdiv(cdiv(M, small ? 64 : 128), 8));
 #define NT_LAUNCH(T, BMv, E) gemm_nt_glds_kernel<T, 64, 2, BMv, E><<<grid, 256, glds_lds_bytes(64, 2, BMv), st>>>((const T*)A, lda, (const T*)W, ldw, M, N, K, *epi)
@@ -685,6 +697,7 @@ int m3l_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, int M
         case EPI_DGELU: NT_LAUNCH(T, BMv, EPI_DGELU); break;   \
         case EPI_PLAIN: NT_LAUNCH(T, BMv, EPI_PLAIN); break;   \
         case EPI_RES32: NT_LAUNCH(T, BMv, EPI_RES32); break;   \
+        case EPI_RES16: NT_LAUNCH(T, BMv, EPI_RES16); break;   \
         default: NT_LAUNCH(T, BMv, EPI_GENERIC); break;        \
     }
         if (dtype == 1) {

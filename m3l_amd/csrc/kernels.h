@@ -33,6 +33,7 @@ struct GemmEpi {
     float alpha;
     int n_bias;            // bias has n_bias valid entries (columns beyond read as 0); 0 -> N
     float* colsum_part;    // [m3l_gemm_nt_colsum_rows(M, N), N] per-row-block column sums of out_t (bias gradient fused into a dgrad) or null
+    const void* res_t;     // bf16 [M, ldc] residual added last (bf16 residual stream: the result goes to out_t), or null; not with res / gelu_u
 };
 
 struct WeightDesc {

@@ -164,16 +164,14 @@ struct RbScope {          // residual mode of the launches issued inside the sco
 };
 bool tf_rb(const m3l_tf_cfg* c, int B, int n, bool fuse) {
     if (!res_bf16_mode() || c->dtype != 1 || fuse || !c->project_out || c->depth < 1) return false;
-    const int M = B * n, D = c->dim, HD = c->heads * 64, mlp = c->mlp_dim;
-    // short sequences: the per-sample block kernels, forward and backward (the MAE encoder)
-    if (m3l_attn_block_supported(1, D, c->heads, n, c->project_out))
-        return m3l_mlp_block_supported(1, D, mlp, n) && m3l_mlp_block_bwd_supported(1, D, mlp, n) && m3l_attn_block_bwd_enabled() &&
-               !(m3l_mlp_t192_short() && m3l_mlp_t192_supported(1, D, mlp, M)) && !(m3l_enc_mega_enabled() & 2);
-    // long sequences: per-sample attention + row-tiled feed-forward kernels, forward and backward (the MAE decoder)
-    return m3l_attn_t192_fwd_supported(1, D, c->heads, n, B) && m3l_attn_tail_mlp_t192_supported(1, D, HD, mlp, M) &&
-           !m3l_mlp_block_bwd_supported(1, D, mlp, n) && m3l_qkv_bwd_t192_supported(1, D, 3 * HD, M);
+    // every kernel a bf16 stack can take has a bf16-residual form — the per-sample blocks, the row tiles, and (since the EPI_RES16 epilogue
+    // of the NT GEMM and the typed dres of ln_bwd) the per-op chain — except the one-launch encoder backward; the residual epilogue of the
+    // out-proj / fc2 GEMMs needs K = heads * 64 / mlp_dim to be a multiple of the 64-element K tile
+    if (c->mlp_dim % 64 != 0) return false;
+    if ((m3l_enc_mega_enabled() & 2) && m3l_attn_block_supported(1, c->dim, c->heads, n, c->project_out)) return false;
+    (void)B;
+    return true;
 }
-
 // which fused kernel (if any) computes the feed-forward half of a layer in the FORWARD — the same decisions as m3l_transformer_fwd below:
 // 0 = per-op GEMMs (h is the operand of the fc2 GEMM: always saved), 1 = per-sample block kernel, 2 = row-tiled kernel
 // (both evaluate the fitted GELU, as every bf16 kernel does).  The backward reads it to know whether h exists and which GELU reproduces it.
@@ -283,6 +281,11 @@ struct TfWs {
     size_t scratch_b, scratch_tn_b;
     size_t total;
 };
+// bf16 residual mode: the fp32 running-gradient buffer w.dx is not used; its memory holds the stack's input as bf16 (kept for the backward
+// of layer 0) and the bf16 gradient of layer 0's input (cast to the caller's fp32 dx_in)
+inline void* rb_xin(const TfWs& w) { return w.dx; }
+inline void* rb_out0(const TfWs& w, size_t M, size_t D) { return reinterpret_cast<char*>(w.dx) + M * D * 2; }
+
 void layer_wgrad_problems(TnProblem* pr, int D, int HD, int mlp, bool project_out, int* np_out) {
     memset(pr, 0, 4 * sizeof(TnProblem));
     int np = 0;
@@ -635,12 +638,12 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, HD) && m3l_gemm_nt_rowln_supported(dt, D, mlp);
     const void* const* tfin = tensors + 11 * c->depth;
     bool final_done = false;
-    // bf16 residual stream: the stack's input as bf16 (kept for the backward of layer 0 in the otherwise unused dxn buffer); from here on
+    // bf16 residual stream: the stack's input as bf16 (kept for the backward of layer 0 in the otherwise unused w.dx buffer); from here on
     // every `float*` of the residual stream points at bf16 data and the launchers are told so
     const bool rb = tf_rb(c, B, n, fuse);
     if (rb && !m3l_call_io()) {          // (m3l_call_io: the caller hands x_in over as bf16 already)
-        if (m3l_cast_f32(1, x_in, (long)M * D, w.dxn, st)) return 1;
-        x = reinterpret_cast<const float*>(w.dxn);
+        if (m3l_cast_f32(1, x_in, (long)M * D, rb_xin(w), st)) return 1;
+        x = reinterpret_cast<const float*>(rb_xin(w));
     }
     RbScope rb_scope(rb);
     // short sequences whose every half layer takes a block kernel: the whole stack in ONE launch (enc_mega.hip)
@@ -706,7 +709,8 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
         } else {
             if (c->project_out) {
                 e = epi0(D);
-                e.bias = out_b; e.res = x; e.out_f32 = L.x1;
+                e.bias = out_b;
+                if (rb) { e.res_t = x; e.out_t = L.x1; } else { e.res = x; e.out_f32 = L.x1; }
                 if (m3l_gemm_nt(dt, L.o, HD, L.wo, HD, M, D, HD, &e, st)) return 1;
             } else {
                 if (m3l_axpy_t(dt, x, L.o, (long)M * D, L.x1, st)) return 1;
@@ -746,7 +750,8 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             if (m3l_gemm_nt_rowln(dt, ROWLN_FWD, L.h, mlp, L.w2, mlp, M, D, mlp, &r, st)) return 1;
         } else {
             e = epi0(D);
-            e.bias = fc2_b; e.res = L.x1; e.out_f32 = L.xout;
+            e.bias = fc2_b;
+            if (rb) { e.res_t = L.x1; e.out_t = L.xout; } else { e.res = L.x1; e.out_f32 = L.xout; }
             if (m3l_gemm_nt(dt, L.h, mlp, L.w2, mlp, M, D, mlp, &e, st)) return 1;
         }
         x = L.xout;
@@ -892,7 +897,7 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
         }
         TfLayer& L = w.L[l];
         const int cur = l % NS, nxt = l ? (l - 1) % NS : 0;
-        const float* xl = l ? w.L[l - 1].xout : ((rb && !m3l_call_io()) ? reinterpret_cast<const float*>(w.dxn) : x_in);
+        const float* xl = l ? w.L[l - 1].xout : ((rb && !m3l_call_io()) ? reinterpret_cast<const float*>(rb_xin(w)) : x_in);
         const void* const* t = tensors + 11 * l;
         float* const* g = grads + 11 * l;
         // set `cur` (dx_t[cur] was written by layer l+1's last kernel, which claimed the set) receives du / dx1_t / dqkv of this layer
@@ -931,8 +936,10 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             e.out_t = w.dxn;
             if (m3l_gemm_nt(dt, w.du[cur], mlp, L.w1T, mlp, M, D, mlp, &e, st)) return 1;             // dxn2 = du W1
             // dx1 = dx + LN2-backward (in place), + compute-type copy, + out-proj bias grad
-            if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, w.dx, w.dx, w.dx1_t[cur], dt,
-                           ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr), nullptr, nullptr, nullptr, 0, st))
+            // (bf16 residual stream: the residual gradient is dx_t[cur] itself, the result exists in the compute type only)
+            if (m3l_ln_bwd(dt, w.dxn, L.x1, M, D, (const float*)t[5], LN_EPS, rb ? reinterpret_cast<const float*>(w.dx_t[cur]) : w.dx,
+                           rb ? nullptr : w.dx, w.dx1_t[cur], dt, ln_slot(2 * l + 1, g[5], g[6], c->project_out ? g[4] : nullptr), nullptr,
+                           nullptr, nullptr, 0, st))
                 return 1;
         }
         // ---- attention: x1 = x + to_out(attn(LN1(x)))
@@ -946,9 +953,9 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             if (rb) {      // the residual gradient is dx1_t itself; the result goes to the next layer's dx_t, or — layer 0 — through d_o to dx_in
                 const bool io = m3l_call_io() && dx_in;
                 if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], nullptr, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
-                                       nullptr, l ? w.dx_t[nxt] : (io ? (void*)dx_in : w.d_o), ln_slot(2 * l, g[0], g[1], db_prev, B), st))
+                                       nullptr, l ? w.dx_t[nxt] : (io ? (void*)dx_in : rb_out0(w, M, D)), ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                     return 1;
-                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(rb_out0(w, M, D), (long)M * D, dx_in, st)) return 1;
             } else if (m3l_attn_block_bwd(D, B, n, w.dx1_t[cur], w.dx, xl, (const float*)t[0], L.qkv, L.o, L.lse, L.woT, L.wqkvT, LN_EPS, w.dqkv[cur],
                                           dx_dst, l ? w.dx_t[nxt] : nullptr, ln_slot(2 * l, g[0], g[1], db_prev, B), st))
                 return 1;
@@ -999,13 +1006,13 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             const int tiles = m3l_qkv_bwd_t192_tiles(D, M);
             if (rb) {
                 // dres = dx1_t of this layer (bf16), result only in the compute type: the next layer's dx_t, or — layer 0 — a bf16 scratch
-                // (d_o, unused on this path) that is cast to the fp32 gradient of the stack's input
+                // (the upper half of the unused w.dx) that is cast to the fp32 gradient of the stack's input
                 const bool io = m3l_call_io() && dx_in;           // the caller takes the input gradient as bf16: no cast
-                void* out_t = l ? w.dx_t[nxt] : (io ? (void*)dx_in : w.d_o);
+                void* out_t = l ? w.dx_t[nxt] : (io ? (void*)dx_in : rb_out0(w, M, D));
                 if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, reinterpret_cast<const float*>(w.dx1_t[cur]), LN_EPS,
                                      nullptr, out_t, ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                     return 1;
-                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(w.d_o, (long)M * D, dx_in, st)) return 1;
+                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(rb_out0(w, M, D), (long)M * D, dx_in, st)) return 1;
             } else if (m3l_qkv_bwd_t192(D, M, 3 * HD, w.dqkv[cur], xl, (const float*)t[0], L.wqkvT, w.dx, LN_EPS, dx_dst, l ? w.dx_t[nxt] : nullptr,
                                         ln_slot(2 * l, g[0], g[1], db_prev, tiles), st))
                 return 1;
@@ -1014,8 +1021,15 @@ int m3l_transformer_bwd_range(const m3l_tf_cfg* c, int B, int n, const float* x_
             e.out_t = w.dxn;
             if (m3l_gemm_nt(dt, w.dqkv[cur], 3 * HD, L.wqkvT, 3 * HD, M, D, 3 * HD, &e, st)) return 1;    // dxn1 = dqkv Wqkv
             if (l && claim_set(nxt)) return 2;
-            if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[nxt] : nullptr, dt,
-                           ln_slot(2 * l, g[0], g[1], db_prev), nullptr, nullptr, nullptr, 0, st))
+            if (rb) {
+                const bool io = m3l_call_io() && dx_in;
+                void* out_t = l ? w.dx_t[nxt] : (io ? (void*)dx_in : rb_out0(w, M, D));
+                if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, reinterpret_cast<const float*>(w.dx1_t[cur]), nullptr, out_t, dt,
+                               ln_slot(2 * l, g[0], g[1], db_prev), nullptr, nullptr, nullptr, 0, st))
+                    return 1;
+                if (l == 0 && dx_in && !io && m3l_cast_bf16_f32(rb_out0(w, M, D), (long)M * D, dx_in, st)) return 1;
+            } else if (m3l_ln_bwd(dt, w.dxn, xl, M, D, (const float*)t[0], LN_EPS, w.dx, dx_dst, l ? w.dx_t[nxt] : nullptr, dt,
+                                  ln_slot(2 * l, g[0], g[1], db_prev), nullptr, nullptr, nullptr, 0, st))
                 return 1;
         }
     }

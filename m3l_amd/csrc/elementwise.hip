@@ -5,6 +5,8 @@
 // reductions over rows go through per-workgroup partial slabs + a fixed-order reduce (bitwise reproducible).
 #include "common.cuh"
 #include "kernels.h"
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -645,10 +647,14 @@ __global__ void vt_tactile_kernel(const TI* __restrict__ in, int B, int th, int 
 // ---------------------------------------------------------------------------------------------------------------
 // random-mask sampling: per (sample, modality) row of noise -> STABLE ascending rank -> masked / unmasked lists
 // (reference: torch.rand(B, n).argsort(-1), models/pretrain_models.py:229-248; tie-break = ascending index)
-__global__ void mask_rank_kernel(const float* __restrict__ noise, int n, int nm, int token_offset, int64_t* __restrict__ masked,
-                                 int masked_ld, int masked_off, int64_t* __restrict__ unmasked, int unmasked_ld, int unmasked_off) {
+// (one launch for all modality groups of a sample: blockIdx.y picks the group's noise / sizes / offsets)
+__global__ void mask_rank_kernel(MaskRankArgs a, int64_t* __restrict__ masked, int masked_ld, int64_t* __restrict__ unmasked,
+                                 int unmasked_ld) {
     extern __shared__ float keys[];
     const int b = blockIdx.x;
+    const MaskRankGroup gr = a.g[blockIdx.y];
+    const float* __restrict__ noise = gr.noise;
+    const int n = gr.n, nm = gr.nm, token_offset = gr.token_offset, masked_off = gr.masked_off, unmasked_off = gr.unmasked_off;
     for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = noise[(long)b * n + i];
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1125,6 +1131,45 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__
     for (int e = lane; e < D; e += 64) d[e] = s[e];
 }
 
+// both modality groups of the heads in one launch: row (b, j), j < cnt0 -> group 0 (row b*cnt0 + j), else group 1 (row b*cnt1 + j - cnt0);
+// the token of (b, j) is idx[b, j]; rows move as 16-byte pieces (D * sizeof(T) % 16 == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const T* __restrict__ src, int N, int D, const int64_t* __restrict__ idx, int idx_ld,
+                                                             int cnt0, int cnt1, int rows, T* __restrict__ dst0, T* __restrict__ dst1) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / (cnt0 + cnt1), j = row % (cnt0 + cnt1);
+    const long pos = idx[(long)b * idx_ld + j];
+    const uint4* s = reinterpret_cast<const uint4*>(src + ((long)b * N + pos) * D);
+    uint4* d = reinterpret_cast<uint4*>(j < cnt0 ? dst0 + ((long)b * cnt0 + j) * D : dst1 + ((long)b * cnt1 + (j - cnt0)) * D);
+    const int pieces = D * (int)sizeof(T) / 16;
+    for (int p = lane; p < pieces; p += 64) d[p] = s[p];
+}
+// ... and the adjoint, times the device scalar *scale (null = 1): the upstream gradient of the loss folded into the scatter
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows2_kernel(const T* __restrict__ src0, const T* __restrict__ src1, int N, int D,
+                                                              const int64_t* __restrict__ idx, int idx_ld, int cnt0, int cnt1, int rows,
+                                                              const float* __restrict__ scale, T* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / (cnt0 + cnt1), j = row % (cnt0 + cnt1);
+    const long pos = idx[(long)b * idx_ld + j];
+    const T* s = j < cnt0 ? src0 + ((long)b * cnt0 + j) * D : src1 + ((long)b * cnt1 + (j - cnt0)) * D;
+    T* d = dst + ((long)b * N + pos) * D;
+    const float sc = scale ? *scale : 1.f;
+    constexpr int E = 16 / (int)sizeof(T);
+    const int pieces = D / E;
+    for (int p = lane; p < pieces; p += 64) {
+        uint4 v = reinterpret_cast<const uint4*>(s)[p];
+        if (scale) {
+            T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+            for (int k = 0; k < E; ++k) e[k] = from_f32<T>(to_f32(e[k]) * sc);
+        }
+        reinterpret_cast<uint4*>(d)[p] = v;
+    }
+}
+
 // masked-patch MSE (pretrain_models.py:260-262,327-340): pred [rows, pdpad] f32 vs raw target patches gathered by the
 // masked indices; part[G] = w * sum (pred - tgt)^2 ; dpred = 2 w (pred - tgt) in compute type (pad columns zero).
 // The target patch is gathered in image order into an LDS copy in patch-vector order (dynamic LDS: WPB x pdpad floats); pred, dpred and
@@ -1322,9 +1367,49 @@ int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, f
     return m3l_reduce_rows(part_ws, G, N, N, out, accumulate, st);
 }
 
+// Weight-copy batching across the modules of one library call chain (the fused step / extractor chain, mae_step.hip): in COLLECT mode a
+// module's m3l_prep_weights only records its matrices (and the module returns right after it: m3l_prep_mode() == 1); m3l_prep_flush
+// issues them as ONE launch per 64 matrices; in SKIP mode the modules then run with their copies in place.  Thread-local, like the
+// other per-call flags (err.hip).  Four launches of 7-16 us spread over the forward become one or two at its start.
+static thread_local int g_prep_mode = 0;
+static thread_local int g_prep_dtype = -1;
+static thread_local std::vector<WeightDesc>* g_prep_list = nullptr;
+int m3l_prep_mode(void) { return g_prep_mode; }
+void m3l_prep_set_mode(int mode) {
+    g_prep_mode = mode;
+    if (mode == 1) {
+        if (!g_prep_list) g_prep_list = new std::vector<WeightDesc>();
+        g_prep_list->clear();
+        g_prep_dtype = -1;
+    }
+}
+int m3l_prep_flush(hipStream_t st) {
+    const int saved = g_prep_mode;
+    g_prep_mode = 0;
+    int rc = 0;
+    if (g_prep_list && !g_prep_list->empty()) {
+        for (size_t i = 0; i < g_prep_list->size() && !rc; i += M3L_WPACK) {
+            WeightPack pk;
+            memset(&pk, 0, sizeof(pk));
+            for (size_t k = i; k < g_prep_list->size() && k < i + M3L_WPACK; ++k) pk.d[pk.count++] = (*g_prep_list)[k];
+            rc = m3l_prep_weights(g_prep_dtype, &pk, st);
+        }
+        g_prep_list->clear();
+    }
+    g_prep_mode = saved;
+    return rc;
+}
+
 int m3l_prep_weights(int dtype, const WeightPack* pack_in, hipStream_t st) {
     if (pack_in->count <= 0) return 0;
     M3L_CHECK(pack_in->count <= M3L_WPACK, "prep_weights: %d matrices in one pack (max %d)", pack_in->count, M3L_WPACK);
+    if (g_prep_mode == 2) return 0;                 // copies already issued by m3l_prep_flush
+    if (g_prep_mode == 1) {
+        M3L_CHECK(g_prep_dtype < 0 || g_prep_dtype == dtype, "prep_weights: modules of one chain disagree on the compute type");
+        g_prep_dtype = dtype;
+        for (int i = 0; i < pack_in->count; ++i) g_prep_list->push_back(pack_in->d[i]);
+        return 0;
+    }
     WeightPack pack = *pack_in;
     int tiles = 0;
     for (int i = 0; i < pack.count; ++i) {
@@ -1542,15 +1627,27 @@ int m3l_vt_load_launch(const void* image_nhwc, int image_u8, int B, int H, int W
     return 0;
 }
 
-int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
-                  int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st) {
-    M3L_CHECK(B > 0 && n > 0 && nm >= 0 && nm <= n, "mask_rank: bad shape B=%d n=%d nm=%d", B, n, nm);
-    M3L_CHECK(n <= 8192, "mask_rank: n=%d too large", n);
-    const int threads = n <= 64 ? 64 : (n <= 128 ? 128 : 256);
-    mask_rank_kernel<<<B, threads, n * sizeof(float), st>>>(noise, n, nm, token_offset, masked, masked_ld, masked_off, unmasked,
-                                                            unmasked_ld, unmasked_off);
+int m3l_mask_rank_groups(const MaskRankArgs* args, int B, int64_t* masked, int masked_ld, int64_t* unmasked, int unmasked_ld, hipStream_t st) {
+    M3L_CHECK(B > 0 && args->count >= 1 && args->count <= M3L_MAX_SENSORS + 1, "mask_rank: B=%d groups=%d", B, args->count);
+    int nmax = 0;
+    for (int i = 0; i < args->count; ++i) {
+        const MaskRankGroup& g = args->g[i];
+        M3L_CHECK(g.n > 0 && g.nm >= 0 && g.nm <= g.n, "mask_rank: bad shape n=%d nm=%d", g.n, g.nm);
+        M3L_CHECK(g.n <= 8192, "mask_rank: n=%d too large", g.n);
+        nmax = std::max(nmax, g.n);
+    }
+    const int threads = nmax <= 64 ? 64 : (nmax <= 128 ? 128 : 256);
+    mask_rank_kernel<<<dim3(B, args->count), threads, nmax * sizeof(float), st>>>(*args, masked, masked_ld, unmasked, unmasked_ld);
     M3L_LAUNCH_CHECK();
     return 0;
+}
+int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
+                  int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st) {
+    MaskRankArgs a;
+    memset(&a, 0, sizeof(a));
+    a.count = 1;
+    a.g[0] = MaskRankGroup{noise, n, nm, token_offset, masked_off, unmasked_off};
+    return m3l_mask_rank_groups(&a, B, masked, masked_ld, unmasked, unmasked_ld, st);
 }
 
 constexpr int PATCH_NV_MAX = 40;
@@ -1696,6 +1793,33 @@ int m3l_gather_rows(int dtype, const void* src, int N, int D, const int64_t* idx
         gather_rows_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>((const bf16*)src, N, D, idx, idx_ld, j0, cnt, rows, (bf16*)dst);
     else
         gather_rows_kernel<float><<<ln_grid(rows), 256, 0, st>>>((const float*)src, N, D, idx, idx_ld, j0, cnt, rows, (float*)dst);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+
+int m3l_gather_rows2(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int cnt0, int cnt1, int B, void* dst0, void* dst1,
+                     hipStream_t st) {
+    const int rows = B * (cnt0 + cnt1);
+    if (rows == 0) return 0;
+    M3L_CHECK((D * (dtype ? 2 : 4)) % 16 == 0, "gather_rows2: rows of %d elements are not 16-byte pieces", D);
+    if (dtype == 1)
+        gather_rows2_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>((const bf16*)src, N, D, idx, idx_ld, cnt0, cnt1, rows, (bf16*)dst0, (bf16*)dst1);
+    else
+        gather_rows2_kernel<float><<<ln_grid(rows), 256, 0, st>>>((const float*)src, N, D, idx, idx_ld, cnt0, cnt1, rows, (float*)dst0, (float*)dst1);
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
+int m3l_scatter_rows2(int dtype, const void* src0, const void* src1, int N, int D, const int64_t* idx, int idx_ld, int cnt0, int cnt1, int B,
+                      const float* scale_dev, void* dst, hipStream_t st) {
+    const int rows = B * (cnt0 + cnt1);
+    if (rows == 0) return 0;
+    M3L_CHECK((D * (dtype ? 2 : 4)) % 16 == 0, "scatter_rows2: rows of %d elements are not 16-byte pieces", D);
+    if (dtype == 1)
+        scatter_rows2_kernel<bf16><<<ln_grid(rows), 256, 0, st>>>((const bf16*)src0, (const bf16*)src1, N, D, idx, idx_ld, cnt0, cnt1, rows, scale_dev,
+                                                                  (bf16*)dst);
+    else
+        scatter_rows2_kernel<float><<<ln_grid(rows), 256, 0, st>>>((const float*)src0, (const float*)src1, N, D, idx, idx_ld, cnt0, cnt1, rows,
+                                                                   scale_dev, (float*)dst);
     M3L_LAUNCH_CHECK();
     return 0;
 }

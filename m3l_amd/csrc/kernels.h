@@ -201,6 +201,10 @@ int m3l_ln_bwd(int dy_dtype, const void* dy, const float* x, int M, int D, const
 int m3l_reduce_rows(const float* part, int G, int stride, int count, float* out, int accumulate, hipStream_t st);
 int m3l_colsum(int dtype, const void* Y, int M, int N, int ld, float* part_ws, float* out, int accumulate, hipStream_t st);
 int m3l_prep_weights(int dtype, const WeightPack* pack_host, hipStream_t st);
+// batching of the modules' weight copies over one call chain: 0 = off, 1 = collect (modules return after recording), 2 = skip (done)
+int m3l_prep_mode(void);
+void m3l_prep_set_mode(int mode);
+int m3l_prep_flush(hipStream_t st);
 int m3l_axpy_t(int dtype, const float* x, const void* o, long count, float* out, hipStream_t st);          // out = x + (float)o
 int m3l_cast_f32(int dtype, const float* x, long count, void* out, hipStream_t st);                        // out = (T)x
 struct m3l_tf_cfg;
@@ -244,6 +248,9 @@ int m3l_adamw_flat(float* p, float* g, float* m, float* v, long n, float lr, flo
                    float max_norm, float* norm_ws, int scale_grads, hipStream_t st);
 int m3l_adam_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
                       int* step_dev, float* bc_dev, hipStream_t st);
+struct MaskRankGroup { const float* noise; int n, nm, token_offset, masked_off, unmasked_off; };
+struct MaskRankArgs { MaskRankGroup g[M3L_MAX_SENSORS + 1]; int count; };
+int m3l_mask_rank_groups(const MaskRankArgs* args, int B, int64_t* masked, int masked_ld, int64_t* unmasked, int unmasked_ld, hipStream_t st);
 int m3l_mask_rank(const float* noise, int B, int n, int nm, int token_offset, int64_t* masked, int masked_ld, int masked_off,
                   int64_t* unmasked, int unmasked_ld, int unmasked_off, hipStream_t st);
 int m3l_patch_ln(int dtype, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B, const float* gamma,
@@ -263,6 +270,10 @@ int k_unshuffle_bwd(const float* dY, const int64_t* unmasked, int nvis, const in
                       int n_tac, int nmod, float* dsrc, float* part_ws, float* dmask_token, float* ddmod, int accumulate, hipStream_t st);
 int m3l_gather_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
                     hipStream_t st);
+int m3l_gather_rows2(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int cnt0, int cnt1, int B, void* dst0, void* dst1,
+                     hipStream_t st);
+int m3l_scatter_rows2(int dtype, const void* src0, const void* src1, int N, int D, const int64_t* idx, int idx_ld, int cnt0, int cnt1, int B,
+                      const float* scale_dev, void* dst, hipStream_t st);
 int m3l_scatter_rows(int dtype, const void* src, int N, int D, const int64_t* idx, int idx_ld, int j0, int cnt, int B, void* dst,
                      hipStream_t st);
 int m3l_mse(int dtype, const float* pred, int pdpad, const PatchGroup* pg, const int64_t* idx, int idx_ld, int j0, int cnt, int B,

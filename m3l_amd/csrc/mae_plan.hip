@@ -472,16 +472,16 @@ int m3l_mask_sample_counts(const m3l_geom* g, int nm_img, int nm_tac, int B, con
     const Geo ge = geo_of(g);
     M3L_CHECK(nm_img >= 0 && nm_img <= ge.n_img && nm_tac >= 0 && nm_tac <= ge.n_tac, "mask_sample: bad counts %d %d", nm_img, nm_tac);
     const int nmask = nm_img + ge.k * nm_tac, nvis = ge.n_img + ge.k * ge.n_tac - nmask;
+    // the image and every tactile sensor in ONE launch (blockIdx.y = modality group)
+    MaskRankArgs a;
+    memset(&a, 0, sizeof(a));
     int ni = 0;
-    if (ge.n_img > 0) {
-        if (m3l_mask_rank(noise[ni++], B, ge.n_img, nm_img, 0, masked, nmask, 0, unmasked, nvis, 0, st)) return 1;
-    }
-    for (int s = 0; s < ge.k; ++s) {
-        if (m3l_mask_rank(noise[ni++], B, ge.n_tac, nm_tac, ge.n_img + s * ge.n_tac, masked, nmask, nm_img + s * nm_tac, unmasked, nvis,
-                          (ge.n_img - nm_img) + s * (ge.n_tac - nm_tac), st))
-            return 1;
-    }
-    return 0;
+    if (ge.n_img > 0) a.g[a.count++] = MaskRankGroup{noise[ni++], ge.n_img, nm_img, 0, 0, 0};
+    for (int s = 0; s < ge.k; ++s)
+        a.g[a.count++] = MaskRankGroup{noise[ni++], ge.n_tac, nm_tac, ge.n_img + s * ge.n_tac, nm_img + s * nm_tac,
+                                       (ge.n_img - nm_img) + s * (ge.n_tac - nm_tac)};
+    if (a.count == 0) return 0;
+    return m3l_mask_rank_groups(&a, B, masked, nmask, unmasked, nvis, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -555,6 +555,7 @@ int embed_run(bool backward, const m3l_geom* g, int D, int dtype, int B, int L, 
             pk.d[pk.count++] = WeightDesc{(const float*)tensors[6 * i + 2], w.g[i].w, w.g[i].wT, D, pd[i], pdp[i], D};
         }
         if (m3l_prep_weights(dtype, &pk, st)) return 1;
+        if (m3l_prep_mode() == 1) return 0;        // collect pass of a call chain (mae_step.hip): the copies are recorded, nothing else runs
     }
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
@@ -633,6 +634,7 @@ int m3l_transformer_fwd(const m3l_tf_cfg* c, int B, int n, const float* x_in, co
             }
         }
     }
+    if (m3l_prep_mode() == 1) return 0;            // collect pass of a call chain (mae_step.hip)
     // LayerNorms fused into the epilogue of the GEMM that produces their input (gemm_rowln.hip) when the row width allows it:
     // out-proj + LN2 of the layer, fc2 + LN1 of the next layer (or the final norm).  Only the very first LN1 is a kernel.
     const bool fuse = use_rowln() && m3l_gemm_nt_rowln_supported(dt, D, HD) && m3l_gemm_nt_rowln_supported(dt, D, mlp);
@@ -1180,6 +1182,7 @@ int m3l_unshuffle_fwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nv
         pk.d[0] = WeightDesc{e2d_w, w.w, w.wT, dd, D, D, dd};
         pk.count = 1;
         if (m3l_prep_weights(dtype, &pk, st)) return 1;
+        if (m3l_prep_mode() == 1) return 0;        // collect pass of a call chain (mae_step.hip)
         GemmEpi e = epi0(dd);
         e.bias = (const float*)tensors[1];
         e.out_f32 = w.proj;
@@ -1187,6 +1190,7 @@ int m3l_unshuffle_fwd(const m3l_geom* g, int D, int dd, int dtype, int B, int nv
         src = w.proj;
     } else {
         M3L_CHECK(D == dd, "unshuffle: enc_to_dec weight missing but encoder dim %d != decoder dim %d", D, dd);
+        if (m3l_prep_mode() == 1) return 0;
     }
     return k_unshuffle_fwd(src, (const float*)tensors[2], unmasked, nvis, masked, nmask, B, dd, ge.n_img, ge.n_tac,
                              (const float*)tensors[3], (const float*)tensors[4], (const float*)tensors[5], dec_in, st);
@@ -1294,11 +1298,12 @@ int m3l_heads_loss_fwd2(const m3l_geom* g, int dd, int dtype, int B, int N, int 
             pk.d[pk.count++] = WeightDesc{(const float*)tensors[2 * i], w.g[i].w, w.g[i].wT, pd[i], dd, dd, pdp[i]};
         }
         if (m3l_prep_weights(dtype, &pk, st)) return 1;
+        if (m3l_prep_mode() == 1) return 0;        // collect pass of a call chain (mae_step.hip)
     }
+    if (m3l_gather_rows2(dtype, dec_t, N, dd, masked, nmask, cnt[0], cnt[1], B, w.g[0].dg, w.g[1].dg, st)) return 1;   // both groups' rows
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
-        if (m3l_gather_rows(dtype, dec_t, N, dd, masked, nmask, j0[i], cnt[i], B, w.g[i].dg, st)) return 1;
         GemmEpi e = epi0(pdp[i]);
         e.bias = (const float*)tensors[2 * i + 1];
         e.n_bias = pd[i];
@@ -1336,21 +1341,24 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
     for (int i = 0; i < 2; ++i) {
         if (cnt[i] == 0) continue;
         const int rows = B * cnt[i];
-        const void* dpred = w.g[i].dpred;                 // d loss / d pred for dloss = 1 (written by the forward)
+        // d loss / d pred for dloss = 1 was written by the forward.  The upstream gradient dloss (a device scalar) scales everything
+        // linearly: on the critical path it is folded into the scatter below (the dgrad GEMM reads the unscaled dpred); the weight /
+        // bias gradients take a scaled copy, made where they run (side stream in deferred-join mode)
+        hipStream_t s2;
+        if (side.fork(st, &s2)) return 2;
+        const void* dpred = w.g[i].dpred;
         if (dloss) {
-            if (m3l_scale_by_dev(dtype, w.g[i].dpred, (long)rows * pdp[i], dloss, w.g[i].dpred_s, st)) return 1;
+            if (m3l_scale_by_dev(dtype, w.g[i].dpred, (long)rows * pdp[i], dloss, w.g[i].dpred_s, s2)) return 1;
             dpred = w.g[i].dpred_s;
         }
-        hipStream_t s2;                                    // head weight / bias gradients: side stream in deferred-join mode
-        if (side.fork(st, &s2)) return 2;
         float* sc = side.on ? w.scratch_side : w.scratch;
         if (m3l_gemm_tn(dtype, dpred, pdp[i], w.g[i].dg, dd, rows, pdp[i], dd, sc, w.scratch_b, grads[2 * i], dd, pd[i], dd, 0, s2)) return 1;
         if (m3l_colsum(dtype, dpred, rows, pd[i], pdp[i], sc, grads[2 * i + 1], 0, s2)) return 1;
         GemmEpi e = epi0(dd);
         e.out_t = w.g[i].ddg;
-        if (m3l_gemm_nt(dtype, dpred, pdp[i], w.g[i].wT, pdp[i], rows, dd, pdp[i], &e, st)) return 1;
-        if (m3l_scatter_rows(dtype, w.g[i].ddg, N, dd, masked, nmask, j0[i], cnt[i], B, d_dec, st)) return 1;
+        if (m3l_gemm_nt(dtype, w.g[i].dpred, pdp[i], w.g[i].wT, pdp[i], rows, dd, pdp[i], &e, st)) return 1;
     }
+    if (m3l_scatter_rows2(dtype, w.g[0].ddg, w.g[1].ddg, N, dd, masked, nmask, cnt[0], cnt[1], B, dloss, d_dec, st)) return 1;
     return side.end();
 }
 
@@ -1472,6 +1480,7 @@ int m3l_earlycnn_fwd(const m3l_cnn_cfg* c, int B, int nsrc, const float* const* 
         pk.count = 1;
         if (m3l_prep_weights(dt, &pk, st)) return 1;
     }
+    if (m3l_prep_mode() == 1) return 0;            // collect pass of a call chain (mae_step.hip)
     ConvSrc cs;
     memset(&cs, 0, sizeof(cs));
     for (int i = 0; i < nsrc; ++i) cs.src[i] = srcs[i];

@@ -187,6 +187,12 @@ Groups groups_of(const m3l_mae_cfg* c) {
     return g;
 }
 
+// weight copies of a whole chain in one launch (elementwise.hip: m3l_prep_set_mode); env M3L_PREP_BATCH=0: every module issues its own
+static int prep_first_pass() {
+    static const int on = getenv("M3L_PREP_BATCH") ? (atoi(getenv("M3L_PREP_BATCH")) > 0 ? 1 : 0) : 1;
+    return on ? 1 : 2;
+}
+static int prep_mode_of(int pass) { return prep_first_pass() == 1 ? pass : 0; }
 // ---- front end forward: -> tokens (B, L, D); idx (B, L) positions of the tokens, or NULL with L == N (all of them, in order)
 int front_fwd(const m3l_mae_cfg* c, const StepDims& d, const FrontWs& f, int B, int L, int cnt_img, const int64_t* idx, const float* image,
               const float* const* tactiles, const void* const* t, float* tokens, hipStream_t st) {
@@ -194,6 +200,7 @@ int front_fwd(const m3l_mae_cfg* c, const StepDims& d, const FrontWs& f, int B, 
     const m3l_cnn_cfg ci = cnn_cfg(c, false), ct = cnn_cfg(c, true);
     if (d.n_img && m3l_earlycnn_fwd(&ci, B, 1, &image, t, f.ws_cnn_img, f.img_tok, st)) return 1;
     if (d.k && m3l_earlycnn_fwd(&ct, B, d.k, tactiles, t + 8, f.ws_cnn_tac, f.tac_tok, st)) return 1;
+    if (m3l_prep_mode() == 1) return 0;            // collect pass: the stems have recorded their weight copies
     float* all = idx ? f.tok_all : tokens;
     if (m3l_tokens_assemble_fwd(&c->geom, d.D, B, f.img_tok, f.tac_tok, t + 16, all, st)) return 1;
     if (idx) return m3l_gather_tokens(all, B, d.N, d.D, idx, L, tokens, st);
@@ -248,6 +255,12 @@ int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const floa
     const Groups g = groups_of(c);
     // mask sampling (pretrain_models.py:223-248) -> the caller's index lists (the backward reads them again)
     if (m3l_mask_sample_counts(&c->geom, d.nm_img, d.nm_tac, B, noise, masked, unmasked, st)) return 1;
+    // every module's compute-type weight copies in one launch per 64 matrices: a collect pass over the chain (each module records its
+    // matrices and returns), the flush, then the chain itself with the copies in place (elementwise.hip: m3l_prep_set_mode)
+    struct PrepReset { ~PrepReset() { m3l_prep_set_mode(0); } } prep_reset;
+    for (int pass = prep_first_pass(); pass <= 2; ++pass) {
+    m3l_prep_set_mode(prep_mode_of(pass));
+    if (pass == 2 && m3l_prep_flush(st)) return 1;
     // patch embed of the visible tokens (:157-216,255-256) / EarlyCNN stems over the frames, then the visible gather (:180-191)
     if (front_fwd(c, d, w.f, B, d.nvis, d.nvis_img, unmasked, image, tactiles, tensors + g.embed, w.tokens, st)) return 1;
     // encoder (:266)
@@ -261,6 +274,13 @@ int m3l_mae_step_fwd(const m3l_mae_cfg* c, int B, const float* image, const floa
     // decoder (:309)
     if (m3l_transformer_fwd(&c->dec, B, d.N, w.dec_in, tensors + g.dec, w.ws_dec, w.dec_t, w.dec32, st)) return 1;
     m3l_set_call_io(0);
+    if (pass == 1) {       // the heads' copies (their other arguments play no part in the collect pass)
+        if (m3l_heads_loss_fwd2(&c->geom, d.dd, d.dt, B, d.N, c->early_conv ? d.N : d.nmask, c->early_conv ? d.n_img : d.nm_img, masked, image, tactiles,
+                                d.dt ? w.dec_t : (void*)w.dec32, tensors + g.heads, w.ws_heads, loss, nullptr, nullptr, nullptr, nullptr, nullptr, st))
+            return 1;
+    }
+    }
+    m3l_prep_set_mode(prep_mode_of(2));      // (the heads below run with their copies in place)
     // heads + masked MSE (:260-262,327-340); early conv: every patch is predicted and scored (:311-322)
     const int64_t* rows = masked;
     int nrows = d.nmask, nrows_img = d.nm_img;
@@ -403,9 +423,15 @@ int m3l_extractor_fwd(const m3l_mae_cfg* c, const m3l_tf_cfg* head, int B, const
     hipStream_t st = (hipStream_t)stream;
     const ExtWs w = ext_layout(c, head, d, B, ws);
     const int g_enc = front_tensors(c), g_head = g_enc + 11 * c->enc.depth + 2;
-    if (front_fwd(c, d, w.f, B, d.N, d.n_img, nullptr, image, tactiles, tensors, w.tokens, st)) return 1;
-    if (m3l_transformer_fwd(&c->enc, B, d.N, w.tokens, tensors + g_enc, w.ws_enc, nullptr, w.enc32, st)) return 1;
-    if (m3l_transformer_fwd(head, B, d.N, w.enc32, tensors + g_head, w.ws_head, nullptr, w.head32, st)) return 1;
+    struct PrepReset { ~PrepReset() { m3l_prep_set_mode(0); } } prep_reset;
+    for (int pass = prep_first_pass(); pass <= 2; ++pass) {        // collect the chain's weight copies, flush them as one launch, run the chain
+        m3l_prep_set_mode(prep_mode_of(pass));
+        if (pass == 2 && m3l_prep_flush(st)) return 1;
+        if (front_fwd(c, d, w.f, B, d.N, d.n_img, nullptr, image, tactiles, tensors, w.tokens, st)) return 1;
+        if (m3l_transformer_fwd(&c->enc, B, d.N, w.tokens, tensors + g_enc, w.ws_enc, nullptr, w.enc32, st)) return 1;
+        if (m3l_transformer_fwd(head, B, d.N, w.enc32, tensors + g_head, w.ws_head, nullptr, w.head32, st)) return 1;
+    }
+    m3l_prep_set_mode(0);
     mean_tokens_kernel<<<B, 256, 0, st>>>(w.head32, d.N, d.D, out);
     M3L_LAUNCH_CHECK();
     return 0;

@@ -1285,6 +1285,138 @@ __global__ __launch_bounds__((TileCfg<D, 12, 1>::THREADS)) void attn_t192_bwd_ke
     }
 }
 
+
+// =============================================================================================================================
+// EXPERIMENT (round 4, EXPERIMENTS.md 5.3): the feed-forward half of a 48-token tile split over `nslice` INDEPENDENT workgroups, each
+// with its own slice of the hidden layer (fc1 rows / fc2 columns [32 c0, 32 (c0 + nc))): 3 token-owning waves + 1 DMA wave, a ring of
+// NST chunk images (24 KiB each), so that 2 (NST = 3) or 3 (NST = 2) workgroups share a CU without sharing a barrier.  Every slice
+// writes its columns of u and h and an fp32 partial of y = h W2^T (no bias, no residual) to ypart[slice][M][192]; the consumer sums
+// the partials in slice order.  Timing probe only (tools/mlp_split_probe.py): nothing in the library calls it.
+template <int NST, int DW = 1> struct SplitCfg {
+    static constexpr int D = 192, KS = 6, ND = 12, BLK = 64 * D, CHUNK = 2 * BLK, PCB = D / 16, PC = 2 * PCB;
+    static constexpr int NSTAGE = NST, STAGE = CHUNK, RING = NST * STAGE, PPW = PC / DW, NCW = 3, ROWS = 48, THREADS = 64 * (3 + DW);
+    static constexpr int B1 = RING;
+    static_assert((NST - 2) * PPW < 64, "vmcnt immediates");
+};
+template <int NST, int DW>
+__global__ __launch_bounds__(64 * (3 + DW)) void mlp_split_fwd_kernel(const bf16* __restrict__ xn2, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                                              const bf16* __restrict__ W2, int M, int mlp, int nslice, bf16* __restrict__ u_out,
+                                                              bf16* __restrict__ h_out, float* __restrict__ ypart, int abl) {
+    using Cf = SplitCfg<NST, DW>;
+    constexpr int D = Cf::D, KS = Cf::KS, ND = Cf::ND, LOOK = NST - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem;
+    float* B1 = reinterpret_cast<float*>(smem + Cf::B1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    // the slices of a tile sit on one XCD (blocks b and b + 8 share one): they read the same xn2 rows
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int slice = idx % nslice, tile = (idx / nslice) * 8 + xcd;
+    const int tiles = (M + Cf::ROWS - 1) / Cf::ROWS;
+    if (tile >= tiles) return;                                // whole workgroup
+    const int nc = (mlp >> 5) / nslice, c0 = slice * nc;      // this slice's 32-wide hidden chunks
+    const long row0 = (long)tile * Cf::ROWS;
+
+    if (wave >= Cf::NCW) {                                     // DMA waves: chunk image = F1 block of W1 rows | F2 block of W2 columns
+        const int dw = wave - Cf::NCW;
+        auto stage = [&](int s) {
+            char* dst = RING + (s % NST) * Cf::STAGE;
+            const int c = c0 + min(s, nc - 1);
+#pragma unroll
+            for (int j = 0; j < Cf::PPW; ++j) {
+                const int p = dw * Cf::PPW + j;
+                if (abl & 2) continue;
+                if (p < Cf::PCB) dma_f1_piece(W1, D, 32 * c, p, dst, lane);
+                else dma_f2_piece(W2, mlp, 32 * c, p - Cf::PCB, dst + Cf::BLK, lane);
+            }
+        };
+        for (int s = 0; s < LOOK && s < nc; ++s) stage(s);
+        for (int s = 0; s < nc; ++s) {
+            const int ahead = min(LOOK - 1, nc - 1 - s);
+            if (ahead >= 2) wait_vmcnt<(LOOK >= 3 ? 2 : 0) * Cf::PPW>();
+            else if (ahead == 1) wait_vmcnt<(LOOK >= 2 ? 1 : 0) * Cf::PPW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                     // stage s landed; the compute waves are done with stage s - 1
+            if (s + LOOK < nc) stage(s + LOOK);
+        }
+        return;
+    }
+    const int tw = wave;
+    const long trow = row0 + 16 * tw + li;
+    const bool ok = trow < M;
+    const long lrow = ok ? trow : (long)M - 1;
+    for (int id = tid; id < 32 * nc; id += 64 * Cf::NCW) B1[id] = b1[32 * c0 + id];
+    if (abl & 16) { for (int q = 0; q < nc; ++q) __builtin_amdgcn_s_barrier(); return; }          // skeleton: barriers only
+    Frag<bf16> xb[KS];
+    load_tok_frags(xn2, lrow, ok, g, xb);
+    f32x4 yacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) yacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < nc; ++st) {
+        __builtin_amdgcn_s_barrier();                         // stage st landed
+        asm volatile("" ::: "memory");
+        const char* Wa = RING + (st % NST) * Cf::STAGE;
+        const char* Wb = Wa + Cf::BLK;
+        f32x4 ua[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        Frag<bf16> fr[PFD][2];
+        auto req = [&](int step, Frag<bf16>(&dst)[2]) {
+            if (step < KS) {
+                dst[0] = frag_f1p(Wa, 0, step, li, g);
+                dst[1] = frag_f1p(Wa, 1, step, li, g);
+            } else {
+                dst[0] = frag_f2(Wb, 2 * (step - KS), li, g);
+                dst[1] = frag_f2(Wb, 2 * (step - KS) + 1, li, g);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) req(i, fr[i]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const Frag<bf16> a0 = fr[ks % PFD][0], a1 = fr[ks % PFD][1];
+            asm volatile("" ::: "memory");
+            req(ks + PFD, fr[ks % PFD]);
+            asm volatile("" ::: "memory");
+            if (!(abl & 4)) {
+            ua[0] = mma16(a0, xb[ks], ua[0]);
+            ua[1] = mma16(a1, xb[ks], ua[1]);
+            }
+        }
+        Frag<bf16> ub, hb;
+        {
+            const f32x4 bias0 = *reinterpret_cast<const f32x4*>(B1 + 32 * st + 8 * g);
+            const f32x4 bias1 = *reinterpret_cast<const f32x4*>(B1 + 32 * st + 8 * g + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ub.v[r] = (bf16)(ua[0][r] + bias0[r]);
+                ub.v[4 + r] = (bf16)(ua[1][r] + bias1[r]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hb.v[j] = (bf16)gelu_fast((float)ub.v[j]);
+            if (ok && !(abl & 1)) {
+                const long o = trow * mlp + 32 * (c0 + st) + 8 * g;
+                *reinterpret_cast<bf16x8*>(u_out + o) = ub.v;
+                if (h_out) *reinterpret_cast<bf16x8*>(h_out + o) = hb.v;
+            }
+        }
+#pragma unroll
+        for (int st2 = KS; st2 < 2 * KS; ++st2) {
+            const Frag<bf16> a0 = fr[st2 % PFD][0], a1 = fr[st2 % PFD][1];
+            asm volatile("" ::: "memory");
+            if (st2 + PFD < 2 * KS) req(st2 + PFD, fr[st2 % PFD]);
+            asm volatile("" ::: "memory");
+            if (!(abl & 4)) {
+            yacc[2 * (st2 - KS)] = mma16(a0, hb, yacc[2 * (st2 - KS)]);
+            yacc[2 * (st2 - KS) + 1] = mma16(a1, hb, yacc[2 * (st2 - KS) + 1]);
+            } else { yacc[2 * (st2 - KS)][0] += (float)hb.v[st2 & 7] + (float)a0.v[0] + (float)a1.v[1]; }
+        }
+    }
+    if (ok && !(abl & 8)) {
+        float* yp = ypart + ((long)slice * M + trow) * D;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) *reinterpret_cast<f32x4*>(yp + 16 * d + 4 * g) = yacc[d];
+    }
+}
+
 }  // namespace
 
 // g_t192: -1 off, otherwise a bit mask: 1 = long sequences (default), 2 = the MLP halves of short sequences too (instead of mlp_block.hip),
@@ -1404,6 +1536,30 @@ template <typename K> static int lds_attr(K kern, size_t bytes) {
 #define T192_RES(...)                                            \
     if (m3l_call_rb()) { using R = bf16; __VA_ARGS__; }           \
     else { using R = float; __VA_ARGS__; }
+
+// timing probe of the split feed-forward forward (see mlp_split_fwd_kernel); nst = ring stages (2: three workgroups per CU, 3: two);
+// dw = DMA waves per workgroup (1 or 2); abl: 1 no u / h stores, 2 no DMA, 4 no MFMA, 8 no partial-output store, 16 barriers only
+extern "C" int m3l_mlp_split_fwd_probe(int M, int mlp, int nslice, int nst, int dw, int abl, const void* xn2, const void* w1, const float* b1,
+                                       const void* w2, void* u, void* h, float* ypart, void* stream) {
+    M3L_CHECK(M > 0 && nslice >= 1 && (mlp >> 5) % nslice == 0 && mlp % 32 == 0 && (nst == 2 || nst == 3) && (dw == 1 || dw == 2),
+              "mlp_split_fwd_probe: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = (M + 47) / 48, per_xcd = ((tiles + 7) / 8) * nslice;
+    const size_t lds = (size_t)nst * SplitCfg<2>::STAGE + (size_t)(mlp / nslice) * 4;
+#define SPLIT_GO(NSTv, DWv, CAP)                                                                                                         \
+    {                                                                                                                                     \
+        LDS_ONCE((mlp_split_fwd_kernel<NSTv, DWv>), CAP);                                                                                  \
+        mlp_split_fwd_kernel<NSTv, DWv><<<8 * per_xcd, 64 * (3 + DWv), lds, st>>>((const bf16*)xn2, (const bf16*)w1, b1, (const bf16*)w2, M, mlp, nslice, \
+                                                                                  (bf16*)u, (bf16*)h, ypart, abl);                        \
+    }
+    if (nst == 2 && dw == 1) SPLIT_GO(2, 1, 64 * 1024)
+    else if (nst == 2) SPLIT_GO(2, 2, 64 * 1024)
+    else if (dw == 1) SPLIT_GO(3, 1, 96 * 1024)
+    else SPLIT_GO(3, 2, 96 * 1024)
+#undef SPLIT_GO
+    M3L_LAUNCH_CHECK();
+    return 0;
+}
 
 int m3l_mlp_t192_fwd(int Dm, int M, int mlp, const void* xn2, const float* x1, const void* w1, const float* b1, const void* w2, const float* b2,
                      void* u, void* h, float* xout, hipStream_t st) {

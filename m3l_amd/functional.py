@@ -134,6 +134,16 @@ def _check_versions(ctx, what):
                                f"(version {t._version}, expected {v})")
 
 
+def _check_inputs(what, tensors, versions):
+    """The backward re-reads the raw observation frames (patches for the patch-LayerNorm backward, the stems' input frames for the direct
+    convolutions' weight gradient): a staging buffer refilled in place between forward and backward would silently give a wrong gradient,
+    so it is refused like a modified parameter."""
+    for i, (t, v) in enumerate(zip(tensors, versions)):
+        if t is not None and t._version != v:
+            raise RuntimeError(f"{what}: input {i} was modified by an inplace operation between forward and backward "
+                               f"(version {t._version}, expected {v}); keep the observation batch unchanged until backward() has run")
+
+
 def _returned(sink, grads):
     return tuple(None for _ in grads) if sink is not None else tuple(grads)
 
@@ -408,7 +418,7 @@ class StepPlan:
     """Everything one fused step needs, assembled by VTMAE._step_fused: cfg (L.MaeCfg), the five tensor groups as one list, which of
     them take a gradient in this call, the inputs and the GradSync (or None)."""
     __slots__ = ("cfg", "tensors", "used", "image", "tactiles", "noises", "sync", "B", "nmask", "nvis", "ws", "keep", "versions", "tens_arr",
-                 "tac_arr", "masked", "unmasked", "extra", "head_cfg")
+                 "tac_arr", "masked", "unmasked", "extra", "head_cfg", "in_versions")
 
 
 def _comm_plan(sync, plan, cfg):
@@ -472,6 +482,7 @@ class MaeStepFn(torch.autograd.Function):
         L.check(lib.m3l_mae_step_fwd(C.byref(cfg), plan.B, L.ptr(plan.image), plan.tac_arr, L.ptr_array(plan.noises), plan.tens_arr,
                                      L.ptr(plan.ws), L.ptr(loss), L.ptr(plan.masked), L.ptr(plan.unmasked), _stream()), "m3l_mae_step_fwd")
         plan.versions = _versions(plan.tensors)
+        plan.in_versions = _versions([plan.image] + list(plan.tactiles))
         plan.noises = None
         ctx.plan = plan
         ctx.n_in = len(tensors)
@@ -486,6 +497,7 @@ class MaeStepFn(torch.autograd.Function):
             if t is not None and t._version != v:
                 raise RuntimeError(f"MaeStepFn: parameter {i} was modified by an inplace operation between forward and backward "
                                    f"(version {t._version}, expected {v})")
+        _check_inputs("MaeStepFn", [plan.image] + list(plan.tactiles), plan.in_versions)
         sync = plan.sync
         grads, direct = _grad_targets((sync, None) if sync is not None else None, plan.tensors, plan.used)
         dloss = _f32c(dloss)
@@ -552,6 +564,7 @@ class ExtractorFn(torch.autograd.Function):
         L.check(lib.m3l_extractor_fwd(C.byref(plan.cfg), C.byref(plan.head_cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws),
                                       L.ptr(out), _stream()), "m3l_extractor_fwd")
         plan.versions = _versions(plan.tensors)
+        plan.in_versions = _versions([plan.image] + list(plan.tactiles))
         ctx.plan = plan
         return out
 
@@ -562,6 +575,7 @@ class ExtractorFn(torch.autograd.Function):
             if t is not None and t._version != v:
                 raise RuntimeError(f"ExtractorFn: parameter {i} was modified by an inplace operation between forward and backward "
                                    f"(version {t._version}, expected {v})")
+        _check_inputs("ExtractorFn", [plan.image] + list(plan.tactiles), plan.in_versions)
         grads = [torch.zeros_like(t) if (t is not None and u) else None for t, u in zip(plan.tensors, plan.used)]
         dout = _f32c(dout)
         L.check(L.lib().m3l_extractor_bwd(C.byref(plan.cfg), C.byref(plan.head_cfg), plan.B, L.ptr(plan.image), plan.tac_arr, plan.tens_arr, L.ptr(plan.ws),
@@ -643,11 +657,13 @@ class EarlyCnnFn(torch.autograd.Function):
         ctx.saved = (cfg, B, nsrc, srcs, tens, ws)
         ctx.params, ctx.sink = tensors, sink
         ctx.versions = _versions(tensors)
+        ctx.in_versions = _versions(srcs)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         cfg, B, nsrc, srcs, tens, ws = ctx.saved
+        _check_inputs("EarlyCnnFn", srcs, ctx.in_versions)
         dout = _f32c(dout)
         grads, direct = _grad_targets(ctx.sink, ctx.params)
         sink = ctx.sink if direct else None

@@ -44,6 +44,9 @@ def _layer_of(name: str) -> int:
                        or name in ("decoder.norm.weight", "decoder.norm.bias")) else 0
 
 
+_RCCL_RANKS = {}          # global ranks (in group order) of the process group the library's one RCCL communicator was created for
+
+
 class GradSync:
     """Flat-buffer, bucketed, backward-overlapped gradient all-reduce (average)."""
 
@@ -130,6 +133,11 @@ class GradSync:
             else:
                 self._fake_comm = torch.cuda.Stream(device=dev, priority=-1 if fc == "1" else 0)
         self.params = [p for _, p in named]
+        # gradients that reach a parameter through autograd's accumulate (learned position tables, a second backward before zero_grad())
+        # count as "received a gradient since zero_grad()" too: FlatAdamW leaves the rest alone, as torch.optim.AdamW skips `.grad is None`
+        for p in self.params:
+            if hasattr(p, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(lambda q, _w=self: _w._written.add(id(q)))
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
         if hasattr(module, "_sinks"):
@@ -156,7 +164,13 @@ class GradSync:
         if not all_agree(lib.m3l_comm_available() == 0):
             warnings.warn("m3l_amd: RCCL not available to the library on every rank (%s); gradient all-reduce through torch.distributed" % L.last_error())
             return False
-        if all_agree(lib.m3l_comm_world() == self.world):      # a live communicator of this process (an earlier GradSync): shared
+        ranks = tuple(dist.get_process_group_ranks(self.group)) if self.group is not None else tuple(range(dist.get_world_size()))
+        if all_agree(lib.m3l_comm_world() == self.world):      # a live communicator of this process (an earlier GradSync): shared ...
+            # ... but only by the SAME set of ranks in the same order (a second GradSync on another process group of equal size
+            # would all-reduce over the wrong ranks without an error)
+            if not all_agree(_RCCL_RANKS.get("ranks") == ranks):
+                raise RuntimeError(f"m3l_amd: the library's RCCL communicator was created for ranks {_RCCL_RANKS.get('ranks')}, this "
+                                   f"GradSync's process group is {ranks}; one communicator per process — set M3L_COMM=c10d for this group")
             return True
         ident = C.create_string_buffer(128)
         ok = 1
@@ -184,6 +198,7 @@ class GradSync:
         if float(probe.item()) != want:
             raise RuntimeError(f"m3l_amd: RCCL probe all-reduce returned {float(probe.item())}, expected {want} for {self.world} ranks")
         self.rccl_probe = float(probe.item())
+        _RCCL_RANKS["ranks"] = ranks
         return True
 
     def zero_grad(self):
@@ -378,7 +393,23 @@ class FlatAdamW(FlatAdam):
         g = self.param_groups[0]
         self.step_count += 1
         mx = float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0
+        # torch.optim.AdamW (the reference's optimizer, pretrain_models.py:675) skips parameters whose .grad is None: under
+        # train_iterations(no_tactile=True), or with the unused patch-embed tensors of early_conv_masking=True, those parameters are neither
+        # decayed nor given moments.  Here every .grad is a (zeroed) view of the flat buffer, so the one launch over the whole buffer would
+        # decay them: parameters that received no gradient since zero_grad() are put back afterwards (their zero gradients do not change the
+        # norm).  [A parameter that receives gradients in some steps only keeps the global step count in its bias correction; torch counts
+        # its own steps.]
+        idle = [q for q in self.sync.params if id(q) not in self.sync._written]
+        saved = []
+        if idle and len(idle) < len(self.sync.params):
+            for q in idle:
+                a, b = self.sync._span[id(q)]
+                saved.append((a, b, self.sync.flat_params[a:b].clone(), self.exp_avg[a:b].clone(), self.exp_avg_sq[a:b].clone()))
         L.check(L.lib().m3l_adamw_step(self.sync.flat_params.data_ptr(), self.sync.flat.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.sync.flat.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                        g["weight_decay"], self.step_count, gscale, mx, self._norm_ws.data_ptr(), 1,
                                        torch.cuda.current_stream().cuda_stream), "m3l_adamw_step")
+        for a, b, pv, mv, vv in saved:
+            self.sync.flat_params[a:b].copy_(pv)
+            self.exp_avg[a:b].copy_(mv)
+            self.exp_avg_sq[a:b].copy_(vv)

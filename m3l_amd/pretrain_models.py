@@ -83,14 +83,29 @@ class Transformer(nn.Module):
                                               FeedForward(dim, mlp_dim, dropout=dropout)]))
 
     def _tensors(self):
+        """The kernels' tensor list (11 per layer + the final norm), cached: ~150 attribute look-ups per call otherwise.  The cache is
+        checked against the modules' parameter dicts on every call (one dict look-up + identity test per entry), so a parameter OBJECT
+        replaced after the first forward (`layer.to_qkv.weight = nn.Parameter(...)`, pruning, a swapped Linear's parameters) is picked up
+        instead of the kernels reading the old tensor.  A swapped sub-MODULE (`attn.to_qkv = nn.Linear(...)`) is not seen by this check:
+        set `transformer._tcache = None` (or call .to() / .float(), which drop it) after surgery of that kind."""
+        if self._tcache is not None:
+            for t, (d, k) in zip(self._tcache, self._tsrc):
+                if d is not None and d.get(k) is not t:
+                    self._tcache = None
+                    break
         if self._tcache is None:
-            t = []
+            t, src = [], []
             for attn, ff in self.layers:
                 out = attn.to_out[0] if self.project_out else None
-                t += [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight,
-                      out.weight if out is not None else None, out.bias if out is not None else None,
-                      ff.net[0].weight, ff.net[0].bias, ff.net[1].weight, ff.net[1].bias, ff.net[4].weight, ff.net[4].bias]
-            self._tcache = t + [self.norm.weight, self.norm.bias]
+                mods = [(attn.norm, "weight"), (attn.norm, "bias"), (attn.to_qkv, "weight"), (out, "weight"), (out, "bias"),
+                        (ff.net[0], "weight"), (ff.net[0], "bias"), (ff.net[1], "weight"), (ff.net[1], "bias"), (ff.net[4], "weight"),
+                        (ff.net[4], "bias")]
+                for m, k in mods:
+                    t.append(getattr(m, k) if m is not None else None)
+                    src.append((m._parameters if m is not None else None, k))
+            t += [self.norm.weight, self.norm.bias]
+            src += [(self.norm._parameters, "weight"), (self.norm._parameters, "bias")]
+            self._tcache, self._tsrc = t, src
         return list(self._tcache)
 
     def _apply(self, fn, *args, **kwargs):

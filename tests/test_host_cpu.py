@@ -178,3 +178,18 @@ def test_comm_entry_points_fail_loudly_before_init():
     rc = lib.m3l_comm_allreduce(None, 0, None)
     assert rc != 0 and "m3l_comm_init" in L.last_error()
     assert lib.m3l_comm_destroy() == 0
+
+
+def test_transformer_tensor_cache_follows_replaced_parameters():
+    """Transformer._tensors() caches the Parameter objects; a parameter replaced after the first call must be picked up."""
+    import torch
+    from m3l_amd.pretrain_models import Transformer
+    tf = Transformer(dim=64, depth=2, heads=2, dim_head=64, mlp_dim=128)
+    first = tf._tensors()
+    assert tf._tensors()[2] is first[2] is tf.layers[0][0].to_qkv.weight
+    new = torch.nn.Parameter(torch.zeros_like(tf.layers[1][0].to_qkv.weight))
+    tf.layers[1][0].to_qkv.weight = new
+    again = tf._tensors()
+    assert again[11 + 2] is new and again[2] is first[2]
+    tf.norm.bias = torch.nn.Parameter(torch.ones_like(tf.norm.bias))
+    assert tf._tensors()[-1] is tf.norm.bias

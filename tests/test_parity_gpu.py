@@ -750,6 +750,48 @@ def test_fused_adamw_clip_matches_torch(max_norm):
                 assert float((p_f.grad - gr[k].grad).abs().max()) <= 1e-4 * gs, ("grad", k)
 
 
+def test_fused_adamw_leaves_gradless_parameters_alone():
+    """torch.optim.AdamW skips parameters whose .grad is None (pretrain_models.py:675 builds it over self.parameters(); under
+    train_iterations(no_tactile=True) the tactile patch embed and to_tactiles never receive a gradient): FlatAdamW must neither decay them
+    nor give them moments, although its one launch runs over the whole flat buffer.  3 steps of the vision-only loss against
+    clip_grad_norm_ + torch AdamW: every parameter equal, the gradient-less ones bit-identical to their initial values."""
+    import copy
+    from m3l_amd.parallel import FlatAdamW, GradSync
+    torch.manual_seed(5)
+    enc = VTT(image_size=32, tactile_size=16, image_patch_size=8, tactile_patch_size=4, dim=64, depth=2, heads=2, mlp_dim=128)
+    ref = VTMAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2).to(DEV)
+    fus = copy.deepcopy(ref)
+    init = {k: v.detach().clone() for k, v in fus.named_parameters()}
+    x = {"image": torch.rand(8, 3, 32, 32, device=DEV), "tactile1": torch.rand(8, 3, 16, 16, device=DEV), "tactile2": torch.rand(8, 3, 16, 16, device=DEV)}
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.1)
+    sync = GradSync(fus)
+    opt_f = FlatAdamW(sync, lr=1e-3, weight_decay=0.1, max_grad_norm=0.5)
+    for it in range(3):
+        noise = [torch.rand(8, 16, device=DEV)]
+        opt_r.zero_grad()
+        (ref(x, use_tactile=False, mask_noise=noise) * 50.0).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt_r.step()
+        opt_f.zero_grad()
+        (fus(x, use_tactile=False, mask_noise=noise) * 50.0).backward()
+        opt_f.step()
+    gr = dict(ref.named_parameters())
+    idle = 0
+    for k, p_f in fus.named_parameters():
+        if id(p_f) not in sync._span:
+            continue
+        if gr[k].grad is None:
+            idle += 1
+            assert torch.equal(p_f.detach(), init[k]), k            # untouched: no decay, no update
+            assert torch.equal(gr[k].detach(), init[k]), k
+            a, b = sync._span[id(p_f)]
+            assert float(opt_f.exp_avg[a:b].abs().max()) == 0.0 and float(opt_f.exp_avg_sq[a:b].abs().max()) == 0.0, k
+        else:
+            scale = float(gr[k].detach().abs().max()) + 1e-12
+            assert float((p_f.detach() - gr[k].detach()).abs().max()) <= 2e-5 * scale + 2e-6, k
+    assert idle >= 6, idle                                          # tactile patch embed (LN, Linear, LN) + to_tactiles at least
+
+
 def test_train_iterations_fused_optimizer():
     """train_args['fused_optimizer']: train_iterations with FlatAdamW (clip fused into the update) lowers the loss like the torch path."""
     import random
@@ -1268,6 +1310,14 @@ def test_gradsync_second_backward_accumulates():
     with torch.no_grad():
         mae.to_pixels.weight.add_(1.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+    # ... and so is an observation batch refilled in place (the backward re-reads the raw frames)
+    with torch.no_grad():
+        mae.to_pixels.weight.sub_(1.0)
+    sync.zero_grad()
+    loss = mae(x, mask_noise=noises)
+    x["image"].mul_(0.5)
+    with pytest.raises(RuntimeError, match="input 0 was modified by an inplace operation"):
         loss.backward()
 
 

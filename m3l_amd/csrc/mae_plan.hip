@@ -339,7 +339,10 @@ TfWs tf_layout(const m3l_tf_cfg* c, int B, int n, void* ws) {
     std::vector<std::pair<int, int>> shapes = {{(int)(3 * HD), (int)D}, {(int)D, (int)HD}, {(int)mlp, (int)D}, {(int)D, (int)mlp}};
     w.scratch_b = scratch_bytes((int)M, shapes, (int)std::max(std::max(mlp, 3 * HD), D));
     for (int j = 1; j < w.wg_batch; ++j) memcpy(pr + j * np, pr, np * sizeof(TnProblem));
-    w.scratch_tn_b = m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * w.wg_batch);
+    // a group may hold fewer layers than wg_batch (the last group of a stack, a chunked backward's range ends), and fewer tiles mean more
+    // splits per tile: the slab workspace is sized for the worst group size
+    w.scratch_tn_b = 0;
+    for (int j = 1; j <= w.wg_batch; ++j) w.scratch_tn_b = std::max(w.scratch_tn_b, m3l_gemm_tn_grouped_ws_bytes((int)M, pr, np * j));
     w.scratch = reinterpret_cast<float*>(a.take(w.scratch_b));
     w.scratch_tn = reinterpret_cast<float*>(a.take(w.scratch_tn_b));
     // partial rows of the row-tiled kernels: sized for EVERY tile shape they may pick (48- / 96- / 128- / 192-row tiles; one fc1-bias row per

@@ -442,10 +442,13 @@ int launch_wgrad(const WgGroup& grp, const WgPlanHost& pl, int M, float* ws, int
 
 size_t m3l_wgrad_ws_bytes(int M, const TnProblem* probs, int count) { return plan_of(M, probs, count, nullptr).ws_bytes; }
 
+// layers per grouped launch: as many as the problem table holds (4).  Every launch writes and re-reads one slab per workgroup (one wave of
+// workgroups = a fixed ~75 MB at 384 x 192 tiles) whatever it multiplies, so more layers per launch means less slab traffic per layer;
+// measured at cfg 2 (decoder: 2 -> 4 layers per launch): same step time, grouped launch 0.44 -> 0.50 of the HBM roof in-step, -150 MB per
+// step; cfg 4 / M3L default +1-2 %.  (More layers per launch only lengthen a split's row range; the caller bounds it by the stack's depth.)
 int m3l_wgrad_layers_per_launch(int M, const TnProblem* layer_probs, int count) {
-    const int tiles = plan_of(M, layer_probs, count, nullptr).tiles_total;
-    const long wgs = (long)tiles * std::max(1, M / 2048);      // workgroups of one layer at >= 2048 rows per split
-    return (int)std::max(1L, std::min(4L, (cu_count() + wgs - 1) / wgs));
+    (void)M; (void)layer_probs; (void)count;
+    return M3L_TN_MAX_PROBLEMS / 4;
 }
 
 int m3l_wgrad_bf16(TnProblem* probs, int count, int M, float* ws, size_t ws_bytes, int accumulate, hipStream_t st, const TnExtra* extras,

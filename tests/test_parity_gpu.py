@@ -623,6 +623,31 @@ def test_chunked_transformer_backward_is_bit_identical(chunk):
             assert torch.equal(p.grad, ref[n]), n
 
 
+def test_chunked_backward_remainder_groups_fit_the_workspace():
+    """A weight-gradient group may hold fewer layers than the stack's layers-per-launch (a chunked backward's range ends, the last group of a
+    stack).  Fewer tiles mean more splits per tile, and at cfg 5's decoder shape (384 / 3 / 4 / 1536, M = 128 x 75) a 1-layer group needs MORE
+    slab workspace than the multi-layer group the workspace used to be sized for ("wgrad: workspace too small").  Chunks of one layer against
+    the unchunked backward: no error, same gradients (different split plans: compared to 2e-3 of the largest entry)."""
+    from m3l_amd import functional as Fn
+    from m3l_amd.pretrain_models import Transformer
+    torch.manual_seed(23)
+    tf = Transformer(dim=384, depth=3, heads=4, dim_head=64, mlp_dim=1536).to(DEV)
+    tf.compute_dtype = "bf16"
+    x = torch.randn(128, 75, 384, device=DEV)
+    dy = torch.randn(128, 75, 384, device=DEV)
+    (tf(x) * dy).sum().backward()
+    ref = {n: p.grad.clone() for n, p in tf.named_parameters()}
+    tf.zero_grad(set_to_none=True)
+    try:
+        Fn.BWD_CHUNK_LAYERS = 1
+        (tf(x) * dy).sum().backward()
+    finally:
+        Fn.BWD_CHUNK_LAYERS = None
+    for n, p in tf.named_parameters():
+        scale = float(ref[n].abs().max()) + 1e-12
+        assert float((p.grad - ref[n]).abs().max()) <= 2e-3 * scale, n
+
+
 def test_fused_gemm_layernorm_path_matches_separate_kernels():
     """gemm_rowln.hip (LayerNorm forward / backward inside the GEMM epilogue; experimental, off by default) must reproduce the
     separate-kernel path: same loss to 1e-5 and every gradient to 2e-3 (fp32), and the bf16 loss within 1e-2 of the oracle."""

@@ -20,5 +20,7 @@ python3 tools/pmc_to_traffic.py $OUT $TAG
 python3 tools/attn_phase_probe.py $TAG > $OUT/attn_phase.log 2>&1 && cp gpurun_out/${TAG}_attn_phases.json $OUT/final/
 # raw traces / counter dumps are tens of MB (gpurun merges at most 64 MiB back): keep only what profiles/ gets
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma
+# the bench line quotes the traffic / phase profiles it finds under profiles/: put the fresh ones there first (this tree is the box's copy)
+cp $OUT/final/${TAG}_traffic.json $OUT/final/${TAG}_attn_phases.json profiles/ 2>/dev/null || true
 python3 bench.py > $OUT/final/${TAG}_bench_n1.json 2> $OUT/bench.log
 tail -c 700 $OUT/final/${TAG}_bench_n1.json

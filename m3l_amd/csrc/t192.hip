@@ -1321,7 +1321,9 @@ __global__ __launch_bounds__(64 * (3 + DW)) void mlp_split_fwd_kernel(const bf16
         const int dw = wave - Cf::NCW;
         auto stage = [&](int s) {
             char* dst = RING + (s % NST) * Cf::STAGE;
-            const int c = c0 + min(s, nc - 1);
+            // abl & 32: every tile starts its ring at a different chunk (do the CUs of an XCD, all pulling the SAME weight bytes at the same
+            // moment, queue on the same L2 channels?) — timing only: the compute waves still take the chunks in order
+            const int c = c0 + ((abl & 32) ? (min(s, nc - 1) + tile) % nc : min(s, nc - 1));
 #pragma unroll
             for (int j = 0; j < Cf::PPW; ++j) {
                 const int p = dw * Cf::PPW + j;

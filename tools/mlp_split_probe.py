@@ -73,4 +73,4 @@ for nslice, nst in ((3, 2), (3, 3), (2, 3), (1, 3), (4, 2), (6, 2)):
 for rep in range(2):
     print(f"mlp_block_fwd                  {timeit(block):7.2f} us")
     for nslice, nst, dw in ((3, 2, 1), (3, 2, 2), (2, 3, 1), (2, 3, 2), (1, 3, 1), (1, 3, 2)):
-        print(f"split nslice {nslice} nst {nst} dw {dw}:  " + "  ".join(f"abl{a}={timeit(lambda: split(nslice, nst, dw, a)):6.2f}" for a in (0, 1, 2, 4, 8, 3, 7, 15, 16)), flush=True)
+        print(f"split nslice {nslice} nst {nst} dw {dw}:  " + "  ".join(f"abl{a}={timeit(lambda: split(nslice, nst, dw, a)):6.2f}" for a in (0, 1, 2, 4, 8, 3, 7, 15, 16, 48, 32)), flush=True)

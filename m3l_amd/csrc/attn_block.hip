@@ -893,7 +893,8 @@ int m3l_attn_block_fwd(int D, int B, int n, const float* x, const float* ln1_w, 
         M3L_HIP(hipFuncSetAttribute((const void*)attn_block_fwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, AbLayout<3>::TOTAL));
         inited = 1;
     }
-    ProfScope prof("attn_block_fwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64, st);
+    ProfScope prof("attn_block_fwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64, st,
+                   (double)B * n * D * (12.0 + 2.0 * (m3l_call_rb() ? 2.0 : 4.0)));       // xn1, qkv, o, xn2 | x, x1
     // (m3l_call_rb(): the residual stream x / x1 of this launch is bf16)
 #define AB_LAUNCH(KT, R)                                                                                                              \
     attn_block_fwd_kernel<KT, R><<<B, AB_THREADS, AbLayout<KT>::TOTAL, st>>>((const R*)x, ln1_w, ln1_b, (const bf16*)wqkv, (const bf16*)wo, bo, ln2_w, \
@@ -921,7 +922,8 @@ int m3l_attn_block_bwd(int D, int B, int n, const void* dx1t, const float* dres,
     }
     M3L_CHECK(D == 128 || D == 192, "attn_block_bwd: D=%d unsupported", D);
     M3L_CHECK(!m3l_call_rb() || dxt_out, "attn_block_bwd: the bf16 residual mode writes its result to dxt_out only");
-    ProfScope prof("attn_block_bwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64, st);
+    ProfScope prof("attn_block_bwd", B, n, D, 2.0 * B * n * (4.0 * D * D) + 10.0 * B * (D / 64) * (double)n * n * 64, st,
+                   (double)B * n * D * (18.0 + (m3l_call_rb() ? 2.0 : 12.0)));            // dx1t, qkv, o, dqkv, dx_t | x (+ fp32: dres, dx)
 #define ABB_LAUNCH(KT, R)                                                                                                               \
     attn_block_bwd_kernel<KT, R><<<B, AB_THREADS, AbBwdLayout<KT>::TOTAL, st>>>((const bf16*)dx1t, (const R*)dres, (const R*)x, ln1_w, (const bf16*)qkv, \
                                                                                (const bf16*)o, lse, (const bf16*)woT, (const bf16*)wqkvT, eps, n,     \

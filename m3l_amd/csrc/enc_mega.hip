@@ -155,7 +155,9 @@ int m3l_enc_fwd_mega(int D, int mlp, int B, int n, const float* x0, const void* 
     MegaFwdPack P;
     memcpy(P.L, layers, (size_t)count * sizeof(MegaFwdLayer));
     P.count = count;
-    ProfScope prof("enc_fwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st);
+    const double rsz = m3l_call_rb() ? 2.0 : 4.0;
+    ProfScope prof("enc_fwd_mega", B, n, count, (double)count * (2.0 * B * n * (4.0 * D * D) + 4.0 * B * (D / 64) * (double)n * n * 64 + 4.0 * B * n * (double)D * mlp), st,
+                   (double)count * B * n * (D * (12.0 + 3.0 * rsz) + mlp * 4.0));        // per layer: xn1, qkv, o, xn2 | x, x1, xout | u, h (each once)
     if (m3l_call_rb()) {
         if (D == 128) enc_fwd_mega_kernel<2, bf16><<<B, AB_THREADS, mega_fwd_lds<2>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());
         else enc_fwd_mega_kernel<3, bf16><<<B, AB_THREADS, mega_fwd_lds<3>(mlp), st>>>(x0, P, eps, n, mlp, m3l_attn_phase_buffer());

@@ -614,7 +614,8 @@ int m3l_mlp_block_bwd(int D, int mlp, int B, int n, const void* dxt, float* dx, 
         M3L_HIP(hipFuncSetAttribute((const void*)mlp_block_bwd_kernel<3, bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb_bwd_lds(3, mlp)));
         inited_mlp = mlp;
     }
-    ProfScope prof("mlp_block_bwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
+    ProfScope prof("mlp_block_bwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st,
+                   (double)B * n * (D * 4.0 + (m3l_call_rb() ? 2.0 : 12.0) * D + mlp * 4.0));
     // (m3l_call_rb(): the residual stream of this launch — x1; dx is then unused — is bf16)
 #define MBB_LAUNCH(KT, R)                                                                                                                  \
     mlp_block_bwd_kernel<KT, R><<<B, MB_THREADS, lds, st>>>((const bf16*)dxt, (R*)dx, (const R*)x1, ln2_w, (const bf16*)u, (const bf16*)w2T,     \
@@ -641,7 +642,8 @@ int m3l_mlp_block_fwd(int D, int mlp, int B, int n, const void* xn2, const float
         inited_mlp = mlp;
     }
     M3L_CHECK(D == 128 || D == 192, "mlp_block: D=%d unsupported", D);
-    ProfScope prof("mlp_block_fwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st);
+    ProfScope prof("mlp_block_fwd", B, n, mlp, 4.0 * B * n * (double)D * mlp, st,
+                   (double)B * n * (D * 2.0 + 2.0 * (m3l_call_rb() ? 2.0 : 4.0) * D + mlp * (h ? 4.0 : 2.0)));
 #define MB_LAUNCH(KT, R)                                                                                                                  \
     mlp_block_fwd_kernel<KT, R><<<B, MB_THREADS, mb_fwd_lds(KT, mlp), st>>>((const bf16*)xn2, (const R*)x1, (const bf16*)w1, b1, (const bf16*)w2, b2, n, \
                                                                            mlp, (bf16*)u, (bf16*)h, (R*)xout)

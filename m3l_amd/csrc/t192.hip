@@ -1567,7 +1567,8 @@ int m3l_mlp_t192_fwd(int Dm, int M, int mlp, const void* xn2, const float* x1, c
                      void* u, void* h, float* xout, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "mlp_t192_fwd: width %d", Dm);
     const int tt = Dm == 192 ? t192_tt(M) : tile_rows(Dm, M) / 16;
-    ProfScope prof("mlp_t192_fwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 2.0 + Dm * 8.0 + mlp * 4.0));
+    const double rsz = m3l_call_rb() ? 2.0 : 4.0;          // bytes of a residual-stream element in this launch
+    ProfScope prof("mlp_t192_fwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 2.0 + 2.0 * rsz * Dm + mlp * (h ? 4.0 : 2.0)));
     ProArgs none;
     memset(&none, 0, sizeof(none));
     T192_DISPATCH(Dm, tt, T192_RES({
@@ -1589,7 +1590,7 @@ int m3l_attn_tail_mlp_t192_fwd(int Dm, int M, int mlp, const void* o, const floa
                                const float* b2, void* u, void* h, float* xout, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "attn_tail_mlp_t192_fwd: width %d", Dm);
     ProfScope prof("attn_tail_mlp_t192_fwd", M, mlp, Dm == 192 ? tall_tt() : tile_rows(Dm, M) / 16, 4.0 * M * (double)Dm * mlp + 2.0 * M * (double)Dm * Dm, st,
-                   (double)M * (Dm * 2.0 + Dm * 4.0 + Dm * 4.0 + Dm * 2.0 + Dm * 8.0 + mlp * 4.0));
+                   (double)M * (Dm * 4.0 + 3.0 * (m3l_call_rb() ? 2.0 : 4.0) * Dm + mlp * (h ? 4.0 : 2.0)));     // o, xn2 | x, x1, xout | u, h
     ProArgs pa = {(const bf16*)o, x, (const bf16*)wo, bo, ln2_w, ln2_b, eps, x1, (bf16*)xn2};
     T192_DISPATCH_FULL(Dm, T192_RES({
         LDS_ONCE((mlp_t192_fwd_kernel<D, TT, CP, 1, R>), (MlpFwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
@@ -1604,7 +1605,8 @@ int m3l_mlp_t192_bwd(int Dm, int M, int mlp, const void* dxt, float* dx, const f
                      const void* w1T, float eps, void* du, void* dx1t, float* cs_part, float* ln_part, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "mlp_t192_bwd: width %d", Dm);
     const int tt = Dm == 192 ? t192_tt(M) : tile_rows(Dm, M) / 16;
-    ProfScope prof("mlp_t192_bwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st, (double)M * (Dm * 4.0 + Dm * 12.0 + mlp * 4.0));
+    ProfScope prof("mlp_t192_bwd", M, mlp, tt, 4.0 * M * (double)Dm * mlp, st,
+                   (double)M * (Dm * 4.0 + (m3l_call_rb() ? 2.0 : 12.0) * Dm + mlp * 4.0));      // dxt, dx1t | x1 (+ fp32: dx read and written) | u, du
     T192_DISPATCH(Dm, tt, T192_RES({
         LDS_ONCE((mlp_t192_bwd_kernel<D, TT, CP, R>), (MlpBwdLayout<D, TT, CP>::total(D == 192 ? 1024 : 2048)));
         M3L_CHECK((MlpBwdLayout<D, TT, CP>::total(mlp)) <= (size_t)160 * 1024, "mlp_t192_bwd: %zu bytes of LDS", (MlpBwdLayout<D, TT, CP>::total(mlp)));
@@ -1640,7 +1642,8 @@ int m3l_qkv_bwd_t192_tiles(int D, int M) { return cdiv(M, D == 192 ? 16 * tall_t
 int m3l_qkv_bwd_t192(int Dm, int M, int K, const void* dqkv, const float* x, const float* ln1_w, const void* wqkvT, const float* dres, float eps,
                      float* dx_out, void* dxt_out, float* ln_part, hipStream_t st) {
     M3L_CHECK(width_ok(Dm), "qkv_bwd_t192: width %d", Dm);
-    ProfScope prof("qkv_bwd_t192", M, K, Dm, 2.0 * M * (double)Dm * K, st, (double)M * (K * 2.0 + Dm * 14.0));
+    ProfScope prof("qkv_bwd_t192", M, K, Dm, 2.0 * M * (double)Dm * K, st,
+                   (double)M * (K * 2.0 + Dm * 2.0 + (m3l_call_rb() ? 4.0 : 12.0) * Dm));                // dqkv | dx_t | x, dres (+ fp32: dx written)
     T192_DISPATCH_FULL(Dm, T192_RES({
         LDS_ONCE((qkv_bwd_t192_kernel<D, TT, R>), (QkvBwdLayout<D, TT>::TOTAL));
         qkv_bwd_t192_kernel<D, TT, R><<<cdiv(M, 16 * TT), TileCfg<D, TT, CP>::THREADS, QkvBwdLayout<D, TT>::TOTAL, st>>>(
@@ -1661,7 +1664,7 @@ int m3l_attn_t192_fwd(int Dm, int B, int n, const float* x, const float* ln_w, c
     M3L_CHECK(Dm == 192 || Dm == 256, "attn_t192_fwd: width %d", Dm);
     const int H = Dm / 64;
     ProfScope prof("attn_t192_fwd", B, n, Dm, 2.0 * B * n * 3.0 * Dm * Dm + 4.0 * B * H * (double)n * n * 64, st,
-                   (double)B * n * (Dm * 4.0 + Dm * 2.0 + 3.0 * Dm * 2.0 + Dm * 2.0));
+                   (double)B * n * (Dm * (m3l_call_rb() ? 2.0 : 4.0) + Dm * 2.0 + 3.0 * Dm * 2.0 + Dm * 2.0));
     if (Dm == 192) {
         T192_RES({
             LDS_ONCE((attn_t192_fwd_kernel<192, 3, R>), (AttnFwdLayout<192>::TOTAL));

@@ -18,6 +18,8 @@ unset M3L_WGRAD_INLINE
 cd $R
 python3 tools/pmc_to_traffic.py $OUT $TAG
 python3 tools/attn_phase_probe.py $TAG > $OUT/attn_phase.log 2>&1 && cp gpurun_out/${TAG}_attn_phases.json $OUT/final/
+# per-kernel-class budget of the step (stand-alone launch times, algorithmic bytes, HBM / MFMA rates): in-library event brackets
+python3 tools/kernel_budget.py > $OUT/final/${TAG}_kernel_budget.json 2> $OUT/budget.log || true
 # raw traces / counter dumps are tens of MB (gpurun merges at most 64 MiB back): keep only what profiles/ gets
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma
 # the bench line quotes the traffic / phase profiles it finds under profiles/: put the fresh ones there first (this tree is the box's copy)

@@ -135,9 +135,15 @@ class GradSync:
         self.params = [p for _, p in named]
         # gradients that reach a parameter through autograd's accumulate (learned position tables, a second backward before zero_grad())
         # count as "received a gradient since zero_grad()" too: FlatAdamW leaves the rest alone, as torch.optim.AdamW skips `.grad is None`
-        for p in self.params:
-            if hasattr(p, "register_post_accumulate_grad_hook"):
-                p.register_post_accumulate_grad_hook(lambda q, _w=self: _w._written.add(id(q)))
+        # (through a weak reference: the hooks outlive this object on the parameters and must not keep its flat buffers alive)
+        import weakref
+        me = weakref.ref(self)
+
+        def _mark(q, _me=me):
+            s = _me()
+            if s is not None:
+                s._written.add(id(q))
+        self._hooks = [p.register_post_accumulate_grad_hook(_mark) for p in self.params if hasattr(p, "register_post_accumulate_grad_hook")]
         self._bucket_ids = sorted({_bucket_of(n) for n, _ in named})
         # direct mode: the module's autograd Functions write straight into the flat buffer and call bucket_done()
         if hasattr(module, "_sinks"):
@@ -200,6 +206,13 @@ class GradSync:
         self.rccl_probe = float(probe.item())
         _RCCL_RANKS["ranks"] = ranks
         return True
+
+    def __del__(self):
+        for h in getattr(self, "_hooks", ()):
+            try:
+                h.remove()
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def zero_grad(self):
         self.flat.zero_()

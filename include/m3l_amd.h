@@ -193,7 +193,8 @@ int m3l_heads_loss_bwd(const m3l_geom* g, int dd, int dtype, int B, int N, int n
                        const void* const* tensors, void* ws, const float* dloss, void* d_dec, float* const* grads, void* stream);
 
 /* ---- the whole MAE step in two calls: VTMAE.forward + loss.backward() (models/pretrain_models.py:146-342 as called at
- * models/ppo_mae.py:262-263, models/sac_mae.py:284-291) for early_conv_masking=False, use_sincosmod_encodings=True.  The module entry
+ * models/ppo_mae.py:262-263, models/sac_mae.py:284-291), for both front ends (patch embed, or the EarlyCNN stems of early_conv_masking=True
+ * with patch sizes 8 / 4: cfg.early_conv) and both position encodings (cfg.learned_pos).  The module entry
  * points above chained in C: same kernels, launch order and results (bit-identical), two host calls instead of ten autograd hops.
  * tensors / grads: ONE array, the groups in this order — embed (15, as m3l_embed_fwd) | encoder transformer (11 * depth + 2) |
  * glue (6, as m3l_unshuffle_fwd) | decoder transformer (11 * depth + 2) | heads (4): m3l_mae_step_num_tensors() entries.

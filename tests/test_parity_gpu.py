@@ -136,7 +136,7 @@ def test_oracle_vit_tiny_shapes(dt, tol):
     P, r = _oracle_run(mae, cfg, x, noises)
     assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"]) and torch.equal(mae.last_mask[1].cpu(), r["unmasked_indices"])
     assert abs(float(loss.detach()) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss.detach()), float(r["loss"]))
-    gtol = 2e-3 if dt == "fp32" else 0.15
+    gtol = 1e-4 if dt == "fp32" else 0.15
     num = den = 0.0
     for name, p in mae.named_parameters():
         ref = P[name].grad
@@ -148,7 +148,7 @@ def test_oracle_vit_tiny_shapes(dt, tol):
         num += float((p.grad.cpu() - ref).double().square().sum())
         den += float(ref.double().square().sum())
     # the whole gradient as one vector: relative L2 distance to the fp32 oracle
-    assert (num / den) ** 0.5 <= (1e-4 if dt == "fp32" else 2e-2), (num / den) ** 0.5
+    assert (num / den) ** 0.5 <= (1e-5 if dt == "fp32" else 8e-3), (num / den) ** 0.5
 
 
 def test_vision_only_and_use_flags():
@@ -487,7 +487,7 @@ def test_extractor_style_consumer_with_grad():
     assert float((gh - PH["t.layers.0.1.net.1.weight"].grad).abs().max()) <= 5e-3 * float(gh.abs().max()) + 1e-8
 
 
-def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gtol=3e-3, seed=0):
+def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gtol=1e-4, seed=0, l2tol=None):
     torch.manual_seed(seed)
     enc = VTT(**enc_kw)
     mae = VTMAE(encoder=enc, **mae_kw).to(DEV)
@@ -502,6 +502,7 @@ def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gt
     assert torch.equal(mae.last_mask[0].cpu(), r["masked_indices"]) and torch.equal(mae.last_mask[1].cpu(), r["unmasked_indices"])
     assert abs(float(loss.detach()) - float(r["loss"])) <= tol * abs(float(r["loss"])), (float(loss.detach()), float(r["loss"]))
     worst = ("", 0.0)
+    num = den = 0.0
     for name, p in mae.named_parameters():
         ref = P[name].grad
         if ref is None:
@@ -510,13 +511,21 @@ def _parity_vs_oracle(enc_kw, mae_kw, B, C, hw_img, hw_tac, k, cfg, tol=1e-4, gt
         err = float((p.grad.cpu() - ref).abs().max()) / max(1e-7, float(ref.abs().max()))
         if err > worst[1]:
             worst = (name, err)
+        num += float((p.grad.cpu() - ref).double().square().sum())
+        den += float(ref.double().square().sum())
+    l2 = (num / max(den, 1e-300)) ** 0.5                    # the whole gradient as one vector: relative L2 distance to the fp32 oracle
     print(f"\n[parity] {mae_kw.get('compute_dtype', 'fp32')} dim {enc_kw['dim']} B {B}: loss rel "
-          f"{abs(float(loss.detach()) - float(r['loss'])) / abs(float(r['loss'])):.2e}, worst grad {worst[0]} {worst[1]:.2e}")
+          f"{abs(float(loss.detach()) - float(r['loss'])) / abs(float(r['loss'])):.2e}, worst grad {worst[0]} {worst[1]:.2e}, grad rel-L2 {l2:.2e}")
     assert worst[1] <= gtol, worst
+    if l2tol is None:
+        l2tol = 1e-5 if mae_kw.get("compute_dtype", "fp32") == "fp32" else 8e-3        # measured 2e-7 / 2.5e-3
+    assert l2 <= l2tol, l2
     return mae
 
 
-@pytest.mark.parametrize("dt,tol,gtol,B", [("fp32", 1e-4, 3e-3, 3), ("bf16", 1e-2, 0.15, 3), ("bf16", 1e-2, 0.15, 40)])
+# per-parameter bound in bf16: 0.15 at B = 3 (the smallest gradients — a stem's conv3 weight — carry 9e-2 of relative noise at three samples),
+# 0.05 at B = 40 (measured 1.7e-2); the whole-gradient rel-L2 is held to 8e-3 at both (measured 2.5e-3)
+@pytest.mark.parametrize("dt,tol,gtol,B", [("fp32", 1e-4, 1e-4, 3), ("bf16", 1e-2, 0.15, 3), ("bf16", 1e-2, 0.05, 40)])
 def test_reference_default_architecture(dt, tol, gtol, B):
     """M3L's own defaults at their real depth (train.py:58-67,128-153): dim 256 / depth 4 / heads 4 / mlp 512, decoder 256 / depth 3 /
     4 heads / mlp 1024, mask 0.95, early_conv_masking=True, frame_stack 4 -> 12 channels (SURVEY section 8 'ref' row); bf16 also takes
